@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes on recipe weights/inputs.
+
+Run in the build container only (needs /root/reference and CPU PyTorch):
+
+    python oracle/gen_golden.py            # all cases
+    python oracle/gen_golden.py micro tiny # a subset
+
+The reference is imported, never copied: model classes from /root/reference/src/models, and
+`flow_matching_sample` / `crossfade_chunks` by parsing /root/reference/infer_test_v3m2.py with `ast` and
+exec-ing only those two function definitions (the file itself cannot be imported: it needs torchaudio and
+dac at top level).  Only inputs-by-recipe metadata and expected OUTPUT VALUES are written to
+the fixtures; the GPU box never sees the reference.
+"""
+from __future__ import annotations
+
+import ast
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import jatsr_amd.recipe as recipe  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_model(cfg, norm="rms", salt=0, dtype=torch.float32):
+    with contextlib.redirect_stdout(io.StringIO()):
+        if norm == "rms":
+            from src.models.jat_audiosr_v3 import JaT_AudioSR_V3 as Cls
+        else:
+            from src.models.jat_audiosr_v2 import JaT_AudioSR_V2 as Cls
+        m = Cls(**cfg, dropout=0.1, drop_path_rate=0.05)
+    sd = {k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg, norm, salt).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(".rope." in k for k in missing), missing   # only the deterministic RoPE buffers
+    return m.to(dtype).eval()
+
+
+def ref_functions():
+    src = open(os.path.join(REF, "infer_test_v3m2.py"), encoding="utf-8").read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef)
+            and n.name in ("flow_matching_sample", "crossfade_chunks")]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "infer_test_v3m2.py", "exec"), ns)
+    return ns["flow_matching_sample"], ns["crossfade_chunks"]
+
+
+def stages_of(model, x_t, t, x_cond, want):
+    """Forward with hooks capturing named intermediate activations."""
+    got = {}
+    hooks = []
+
+    def grab(name):
+        return lambda mod, inp, out: got.__setitem__(name, out.detach().clone())
+
+    hooks.append(model.patch_embed.register_forward_hook(grab("patch_embed")))
+    hooks.append(model.t_embedder.register_forward_hook(grab("t_emb")))
+    for i in want:
+        hooks.append(model.blocks[i].register_forward_hook(grab(f"block{i}")))
+    hooks.append(model.final_layer[0].register_forward_hook(grab("final_norm")))
+    with torch.no_grad():
+        out = model(x_t, t, x_cond)
+    for h in hooks:
+        h.remove()
+    return out, got
+
+
+def sub(a, s1, s2):
+    return np.ascontiguousarray(a[:, ::s1, ::s2])
+
+
+def forward_case(name, cfg_name, B, T, t_list, norm="rms", full=False, s_out=(37, 5), s_st=(3, 11),
+                 salt=0, blocks=None):
+    cfg = recipe.CONFIGS[cfg_name]
+    m = ref_model(cfg, norm, salt)
+    C = cfg["input_channels"]
+    x_t, x_c = recipe.make_latents(B, C, T, salt=salt + 100)
+    t = np.asarray(t_list, dtype=np.float32)
+    depth = cfg["depth"]
+    blocks = blocks if blocks is not None else sorted({0, depth // 2 - 1 if depth > 2 else 0, depth - 1})
+    out, st = stages_of(m, torch.from_numpy(x_t), torch.from_numpy(t), torch.from_numpy(x_c), blocks)
+    # fp64 run of the same reference: ground truth used to state the fp32 noise floor
+    m64 = ref_model(cfg, norm, salt, dtype=torch.float64)
+    with torch.no_grad():
+        out64 = m64(torch.from_numpy(x_t).double(), torch.from_numpy(t).double(), torch.from_numpy(x_c).double())
+    out, out64 = out.numpy(), out64.numpy()
+    rec = {"meta": json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, t=[float(v) for v in t], norm=norm,
+                                   salt=salt, full=full, s_out=s_out, s_st=s_st, blocks=blocks,
+                                   torch=torch.__version__)),
+           "out_l2": np.float64(np.linalg.norm(out64)),
+           "out_f32_vs_f64_rel": np.float64(np.linalg.norm(out - out64) / np.linalg.norm(out64))}
+    rec["out"] = out if full else sub(out, *s_out)
+    rec["out64"] = out64 if full else sub(out64, *s_out)
+    for k, v in st.items():
+        v = v.numpy()
+        rec["st_" + k] = v if (full or v.ndim == 2) else sub(v, *s_st)
+        rec["l2_" + k] = np.float64(np.linalg.norm(v.astype(np.float64)))
+    np.savez_compressed(os.path.join(GOLD, f"fwd_{name}.npz"), **rec)
+    print(f"[golden] fwd_{name}: out{out.shape} l2={rec['out_l2']:.4f} f32-vs-f64 rel={rec['out_f32_vs_f64_rel']:.2e}")
+
+
+def sampler_case(name, cfg_name, B, T, steps, cfg_scale, salt=0, s_out=(37, 5), full=False):
+    fms, _ = ref_functions()
+    cfg = recipe.CONFIGS[cfg_name]
+    m = ref_model(cfg, "rms", salt)
+    C = cfg["input_channels"]
+    lr = recipe.gaussian("lr_latent", (B, C, T), salt + 200)
+    z0 = recipe.gaussian("z0", (B, C, T), salt + 201)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: torch.from_numpy(z0).clone()   # inject z0 at infer_test_v3m2.py:133
+    try:
+        z = fms(m, torch.from_numpy(lr), num_steps=steps, cfg_scale=cfg_scale, device="cpu", verbose=False)
+    finally:
+        torch.randn = real_randn
+    z = z.numpy()
+    rec = {"meta": json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, steps=steps, cfg_scale=cfg_scale,
+                                   salt=salt, s_out=s_out, full=full, torch=torch.__version__)),
+           "z": z if full else sub(z, *s_out), "z_l2": np.float64(np.linalg.norm(z.astype(np.float64)))}
+    np.savez_compressed(os.path.join(GOLD, f"sampler_{name}.npz"), **rec)
+    print(f"[golden] sampler_{name}: z{z.shape} l2={rec['z_l2']:.4f}")
+
+
+def misc_case():
+    _, xf = ref_functions()
+    rec = {"linspace51": torch.linspace(0.0, 1.0, 51).numpy(),
+           "linspace11": torch.linspace(0.0, 1.0, 11).numpy(),
+           "linspace8": torch.linspace(0.0, 1.0, 8).numpy()}
+    chunks = [recipe.gaussian("chunk", (1, 6, n), i) for i, n in enumerate((40, 40, 23))]
+    rec["xfade_ov8"] = xf([torch.from_numpy(c) for c in chunks], 8).numpy()
+    rec["xfade_ov0"] = xf([torch.from_numpy(c) for c in chunks], 0).numpy()
+    rec["xfade_single"] = xf([torch.from_numpy(chunks[0])], 8).numpy()
+    # zero-init property (jat_audiosr_v3.py:395-404): a freshly constructed model outputs exact zeros
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.models.jat_audiosr_v3 import JaT_AudioSR_V3
+        m = JaT_AudioSR_V3(**recipe.CONFIGS["micro"]).eval()
+    x_t, x_c = recipe.make_latents(1, 32, 16, salt=7)
+    with torch.no_grad():
+        z = m(torch.from_numpy(x_t), torch.tensor([0.3]), torch.from_numpy(x_c))
+    rec["zero_init_absmax"] = np.float64(z.abs().max().item())
+    # flop counter on the reference (closed-form check)
+    from torch.utils.flop_counter import FlopCounterMode
+    m = ref_model(recipe.CONFIGS["tiny"])
+    x_t, x_c = recipe.make_latents(2, 1024, 128, salt=3)
+    with FlopCounterMode(display=False) as fc, torch.no_grad():
+        m(torch.from_numpy(x_t), torch.tensor([0.1, 0.9]), torch.from_numpy(x_c))
+    rec["flops_tiny_B2_T128"] = np.int64(fc.get_total_flops())
+    np.savez_compressed(os.path.join(GOLD, "misc.npz"), **rec)
+    print(f"[golden] misc: zero_init_absmax={rec['zero_init_absmax']} flops_tiny={rec['flops_tiny_B2_T128']}")
+
+
+def main(which):
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 8)
+    allc = not which
+    if allc or "micro" in which:
+        forward_case("micro_T24", "micro", 2, 24, [0.02, 0.98], full=True)
+        forward_case("micro_T22_pad", "micro", 3, 22, [0.0, 0.5, 1.0], full=True, salt=1)
+        forward_case("micro_ln_T24", "micro", 2, 24, [0.02, 0.98], norm="ln", full=True, salt=2)
+        sampler_case("micro_cfg3", "micro", 2, 24, 50, 3.0, full=True)
+        sampler_case("micro_nocfg", "micro", 2, 22, 10, 1.0, full=True, salt=1)
+    if allc or "tiny" in which:
+        forward_case("tiny_T128", "tiny", 2, 128, [0.0, 0.5])
+        forward_case("tiny_T516_pad", "tiny", 2, 518, [0.25, 1.0], salt=1)
+        sampler_case("tiny_cfg3", "tiny", 1, 64, 50, 3.0)
+    if allc or "v3mod2" in which:
+        forward_case("v3mod2_T512", "v3mod2", 2, 512, [0.02, 0.98])
+        forward_case("v3mod2_T1378", "v3mod2", 1, 1378, [0.5], salt=1, s_out=(37, 13))
+    if allc or "misc" in which:
+        misc_case()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
