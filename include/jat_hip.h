@@ -1,0 +1,136 @@
+/*
+ * jat_hip.h — C ABI of libjat_hip.so: the MI355X (gfx950) DiT flow-matching sampling path of JaTSR.
+ *
+ * The reference (HUSRCF/JaTSR) has no plugin/FFI layer; the interface this library replaces is the
+ * Python module API of src/models/jat_audiosr_v3.py and the sampler in infer_test_v3m2.py.
+ * Each entry point cites the reference symbol it stands in for (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *   - tensors are dense row-major fp32 unless a comment says otherwise;
+ *   - every call enqueues its work on the caller's hipStream_t (passed as void*) and returns without
+ *     synchronising; no allocation happens after *_create / *_load_weights;
+ *   - return value: 0 = ok, negative = error (JAT_E_*), message via jat_last_error() (thread-local);
+ *   - nothing throws across the ABI; a handle is used from one host thread at a time (one per device).
+ */
+#ifndef JAT_HIP_H
+#define JAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JAT_OK 0
+#define JAT_E_INVALID (-1)   /* bad argument / unsupported shape (mirrors ValueError / AssertionError) */
+#define JAT_E_HIP (-2)       /* a HIP runtime call failed */
+#define JAT_E_STATE (-3)     /* weights not loaded, workspace too small, ... */
+#define JAT_E_SEQLEN (-4)    /* N = ceil(T/4) > max_len (2048): jat_audiosr_v3.py:451-452 raises ValueError */
+
+#define JAT_NORM_RMS_W 0        /* nn.RMSNorm(D, eps=1e-6) with weight: jat_audiosr_v3.py:261,264,384 */
+#define JAT_NORM_LN_NOAFFINE 1  /* nn.LayerNorm(D, elementwise_affine=False, eps=1e-6): jat_audiosr_v2.py:242,245,361 */
+
+typedef struct jat_model jat_model;
+typedef struct jat_sampler jat_sampler;
+
+/* Constructor arguments of JaT_AudioSR_V3 (jat_audiosr_v3.py:320-331); dropout / drop_path are
+ * training-only and have no effect on this (eval) path. */
+typedef struct jat_config {
+  int32_t input_channels;  /* 1024 */
+  int32_t cond_channels;   /* 1024 */
+  int32_t patch_len;       /* 4 (the only supported value) */
+  int32_t hidden_size;     /* D, multiple of 256 */
+  int32_t depth;
+  int32_t num_q_heads;     /* hidden_size / num_q_heads must be 64 */
+  int32_t num_kv_heads;
+  int32_t bottleneck_dim;  /* multiple of 128 */
+  int32_t mlp_hidden;      /* int(hidden_size * mlp_ratio), multiple of 128 */
+  int32_t norm_mode;       /* JAT_NORM_* */
+} jat_config;
+
+/* One named fp32 parameter of the reference state_dict (device pointer, [out,in] row-major for Linear
+ * weights).  Names are the reference's keys, e.g. "blocks.3.attn.q_proj.weight". */
+typedef struct jat_tensor_ref {
+  const char* name;   /* [host] */
+  const float* data;  /* device */
+  int64_t numel;
+} jat_tensor_ref;
+
+const char* jat_last_error(void);
+int jat_version(void);
+
+/* ---- model: JaT_AudioSR_V3 / _V2 (jat_audiosr_v3.py:311-471) ------------------------------------ */
+int jat_model_create(const jat_config* cfg, jat_model** out);
+void jat_model_destroy(jat_model* m);
+/* == load_state_dict (infer_test_v3m2.py:61-74): borrows the fp32 tensors for the duration of the call
+ * (synchronises `stream` before returning), packs them once into bf16 (fused [Wq;Wk;Wv], all layers'
+ * adaLN weights concatenated) plus fp32 copies of biases / norm weights / t_embedder.  Unknown names
+ * (e.g. the persistent RoPE buffers) are ignored; missing names are an error unless norm weights in
+ * LN_NOAFFINE mode. */
+int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, void* stream);
+int jat_model_workspace_bytes(const jat_model* m, int32_t B, int32_t T, size_t* out);
+
+/* == JaT_AudioSR_V3.forward(x_t, t, x_cond) in eval mode (jat_audiosr_v3.py:422-471).
+ * x_t, x_cond, x_pred: [B, input_channels, T]; t: [B].  Pads T to a multiple of 4 internally (:435-439),
+ * trims on output (:468-469).  Inputs are not modified. */
+int jat_forward(jat_model* m, const float* x_t, const float* t, const float* x_cond, float* x_pred,
+                int32_t B, int32_t T, void* workspace, size_t workspace_bytes, void* stream);
+
+/* == DiTBlock_GQA.forward(x, t_emb) (jat_audiosr_v3.py:284-308): x,y [B,N,D], t_emb [B,D]. */
+int jat_block_forward(jat_model* m, int32_t layer, const float* x, const float* t_emb, float* y,
+                      int32_t B, int32_t N, void* workspace, size_t workspace_bytes, void* stream);
+/* == GroupedQueryAttention.forward(x) (jat_audiosr_v3.py:144-184): x,y [B,N,D]. */
+int jat_attn_forward(jat_model* m, int32_t layer, const float* x, float* y, int32_t B, int32_t N,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* == t_embedder(t) (jat_audiosr_v3.py:364-369,455): t [B] -> t_emb [B,D]. */
+int jat_time_embed(jat_model* m, const float* t, float* t_emb, int32_t B, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ---- sampler: flow_matching_sample (infer_test_v3m2.py:107-185) ------------------------------------ */
+/* Builds, for a fixed (B, T, steps, cfg_scale): the schedule linspace(0,1,steps+1) (:136) as host floats,
+ * the [steps, depth, 6D] adaLN modulation table (all rows of a step share one t, :150), private state
+ * buffers, and ONE hipGraph holding all `steps` CFG double-batch forwards + Euler updates. */
+int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t steps, float cfg_scale,
+                       jat_sampler** out);
+void jat_sampler_destroy(jat_sampler* s);
+/* lr_latent, z0_noise, z_out: [B, C, T].  z0_noise replaces torch.randn at :133 (caller-supplied so that
+ * results are reproducible).  use_graph=0 replays the same kernels eagerly (debug / A-B timing). */
+int jat_sampler_run(jat_sampler* s, const float* lr_latent, const float* z0_noise, float* z_out,
+                    int32_t use_graph, void* stream);
+/* One CFG combine + Euler update (infer_test_v3m2.py:161-179) in place on z [B,C,T];
+ * x_pred_2B = [cond; uncond] is [2B,C,T] when cfg_scale != 1, else [B,C,T]. */
+int jat_cfg_euler_step(const float* x_pred_2B, float* z, float cfg_scale, float t, float dt, int32_t B,
+                       int32_t C, int32_t T, void* stream);
+
+/* ---- chunk driver pieces (infer_test_v3m2.py:188-233, 381-394) ------------------------------------- */
+/* out[c,t] = (in[c,t] - mean[c]) / std[c]   (inverse=0)  |  in[c,t]*std[c] + mean[c]   (inverse=1) */
+int jat_channel_affine(const float* in, const float* mean, const float* std, float* out, int32_t B,
+                       int32_t C, int32_t T, int32_t inverse, void* stream);
+/* Linear crossfade of `prev` tail with `cur` head over `overlap` frames into out [rows, Tp+Tc-overlap]. */
+int jat_crossfade_pair(const float* prev, int32_t Tp, const float* cur, int32_t Tc, int32_t overlap,
+                       float* out, int32_t rows, void* stream);
+
+/* ---- per-kernel entry points (unit parity tests; bench roofline leg) --------------------------------- */
+/* y_bf16[M,D] = norm(x[M,D]) (* w) * (1 + scale[b]) + shift[b], b = row / rows_per_batch;
+ * shift/scale may be NULL (no modulation); mod_bstride = element stride between batches (0 = shared). */
+int jat_k_norm_modulate(const float* x, const float* w, const float* shift, const float* scale,
+                        int64_t mod_bstride, uint16_t* y_bf16, int32_t M, int32_t D, int32_t rows_per_batch,
+                        int32_t norm_mode, void* stream);
+/* C[M,N] (+bias) = A_bf16[M,K] * W_bf16[N,K]^T ; epilogue: 0 = fp32 out, 1 = bf16 out, 2 = bf16 GELU(erf),
+ * 3 = fp32 out += gate[b]*(acc+bias) (gate [B, N] with stride gate_bstride).  variant selects the tile
+ * configuration (0 = default). */
+int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N,
+               int32_t K, int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch,
+               int32_t variant, void* stream);
+/* GQA attention on bf16 q[M,Hq*64], k[M,Hkv*64], vt[B,Hkv,64,Npad] -> o[M,Hq*64]; softmax(q k^T / 8) v. */
+int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t B,
+                    int32_t N, int32_t Hq, int32_t Hkv, int32_t Npad, void* stream);
+/* fp32 -> bf16 (round-to-nearest-even) */
+int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAT_HIP_H */

@@ -5,20 +5,21 @@ Host side keeps the reference's module API (`JaT_AudioSR_V3`, `DiTBlock_GQA`, `G
 kernels behind the C ABI declared in `include/jat_hip.h` (`csrc/libjat_hip.so`).  There is no CPU fallback:
 calling a compute entry point without the built library or without a GPU raises.
 """
+import importlib as _importlib
+
 from . import recipe  # noqa: F401  (numpy only)
 
-__all__ = ["recipe"]
+_LAZY = {
+    "JaT_AudioSR_V3": "model", "JaT_AudioSR_V2": "model", "DiTBlock_GQA": "model",
+    "GroupedQueryAttention": "model", "load_model": "model",
+    "flow_matching_sample": "sampler", "crossfade_chunks": "sampler", "chunk_plan": "sampler",
+    "sample_long": "sampler", "Sampler": "sampler", "channel_affine": "sampler",
+}
+__all__ = ["recipe"] + sorted(_LAZY)
 
 
 def __getattr__(name):
     # torch-dependent modules are imported lazily so that `import jatsr_amd.recipe` stays numpy-only
-    if name in ("JaT_AudioSR_V3", "JaT_AudioSR_V2", "DiTBlock_GQA", "GroupedQueryAttention", "model"):
-        from . import model as _m
-        return _m if name == "model" else getattr(_m, name)
-    if name in ("flow_matching_sample", "crossfade_chunks", "chunk_plan", "sample_long", "sampler"):
-        from . import sampler as _s
-        return _s if name == "sampler" else getattr(_s, name)
-    if name in ("lib", "_lib"):
-        from . import _lib
-        return _lib
-    raise AttributeError(name)
+    if name in _LAZY:
+        return getattr(_importlib.import_module(f"{__name__}.{_LAZY[name]}"), name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

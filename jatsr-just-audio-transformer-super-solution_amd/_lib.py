@@ -1,0 +1,101 @@
+"""ctypes binding of libjat_hip.so (C ABI: include/jat_hip.h).
+
+There is deliberately no fallback: if the library is not built, or a compute entry point is called
+without a GPU, this raises — the product path never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libjat_hip.so")
+
+JAT_OK, JAT_E_INVALID, JAT_E_HIP, JAT_E_STATE, JAT_E_SEQLEN = 0, -1, -2, -3, -4
+NORM_RMS_W, NORM_LN_NOAFFINE = 0, 1
+
+
+class JatConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "input_channels", "cond_channels", "patch_len", "hidden_size", "depth", "num_q_heads",
+        "num_kv_heads", "bottleneck_dim", "mlp_hidden", "norm_mode")]
+
+
+class JatTensorRef(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/jat_hip.h declares
+_VP, _I32, _I64, _F32, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    "jat_last_error": (C.c_char_p, []),
+    "jat_version": (C.c_int, []),
+    "jat_model_create": (C.c_int, [C.POINTER(JatConfig), C.POINTER(_VP)]),
+    "jat_model_destroy": (None, [_VP]),
+    "jat_model_load_weights": (C.c_int, [_VP, C.POINTER(JatTensorRef), _I32, _VP]),
+    "jat_model_workspace_bytes": (C.c_int, [_VP, _I32, _I32, C.POINTER(_SZ)]),
+    "jat_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP, _SZ, _VP]),
+    "jat_block_forward": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I32, _I32, _VP, _SZ, _VP]),
+    "jat_attn_forward": (C.c_int, [_VP, _I32, _VP, _VP, _I32, _I32, _VP, _SZ, _VP]),
+    "jat_time_embed": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _SZ, _VP]),
+    "jat_sampler_create": (C.c_int, [_VP, _I32, _I32, _I32, _F32, C.POINTER(_VP)]),
+    "jat_sampler_destroy": (None, [_VP]),
+    "jat_sampler_run": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP]),
+    "jat_cfg_euler_step": (C.c_int, [_VP, _VP, _F32, _F32, _F32, _I32, _I32, _I32, _VP]),
+    "jat_channel_affine": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "jat_crossfade_pair": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _VP, _I32, _VP]),
+    "jat_k_norm_modulate": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "jat_k_gemm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _I64, _I32, _I32, _VP]),
+    "jat_k_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "jat_k_cast_bf16": (C.c_int, [_VP, _VP, _I64, _VP]),
+}
+
+_lib = None
+
+
+class JatError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libjat_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JatError(f"{LIB_PATH} not found: build it first (`python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` or `make -C {os.path.dirname(LIB_PATH)}`); there is no CPU fallback")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int):
+    """Translate a C-ABI return code into the exception the reference would raise at that point."""
+    if rc == JAT_OK:
+        return
+    msg = lib().jat_last_error().decode("utf-8", "replace")
+    if rc == JAT_E_SEQLEN:
+        raise ValueError(msg)              # jat_audiosr_v3.py:451-452
+    if rc == JAT_E_INVALID:
+        raise ValueError(msg)
+    raise JatError(f"libjat_hip error {rc}: {msg}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise JatError("jatsr_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False and there is "
+                       "no CPU fallback on the product path")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

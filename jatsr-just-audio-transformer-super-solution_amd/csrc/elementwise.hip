@@ -1,0 +1,332 @@
+// HBM-bound row-wise and elementwise kernels of the DiT sampling path (gfx950).
+// All of them stream 16 B per lane (cdna_hip_programming.md Guideline 13) and reduce with 64-wide
+// wavefront shuffles; none is GEMM-shaped.
+#include "jat_kernels.h"
+
+__device__ __forceinline__ unsigned short f2bf_e(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ uint2 pack4_e(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = (unsigned)f2bf_e(a) | ((unsigned)f2bf_e(b) << 16);
+  r.y = (unsigned)f2bf_e(c) | ((unsigned)f2bf_e(d) << 16);
+  return r;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- fused norm + adaLN modulate -> bf16 ----------------------------------------------------------
+// y = norm(x) * w * (1 + scale[b]) + shift[b]     (jat_audiosr_v3.py:297-298, 303-304; final norm :384)
+// mode 0: RMSNorm(eps 1e-6, weight) ; mode 1: LayerNorm(eps 1e-6, no affine) ; mode 2: plain cast.
+// One wave per row; the row (D <= 2048 floats) lives in registers between the statistics and the write.
+__global__ void __launch_bounds__(256) norm_modulate_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ scale, int64_t mod_bstride,
+                                                            bf16_t* __restrict__ y, int M, int D, int ntok, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = D >> 8;  // 256 floats per chunk (64 lanes x float4)
+  const float* xr = x + (int64_t)row * D + lane * 4;
+  float4 v[8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c < nch) {
+      v[c] = *(const float4*)(xr + c * 256);
+      s1 += v[c].x + v[c].y + v[c].z + v[c].w;
+      s2 += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+    }
+  }
+  float mu = 0.f, rstd = 1.f;
+  if (mode == 0) {
+    s2 = wave_sum(s2);
+    rstd = rsqrtf(s2 / (float)D + 1e-6f);
+  } else if (mode == 1) {
+    s1 = wave_sum(s1);
+    mu = s1 / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nch) {
+        const float a = v[c].x - mu, b2 = v[c].y - mu, c2 = v[c].z - mu, d2 = v[c].w - mu;
+        var += a * a + b2 * b2 + c2 * c2 + d2 * d2;
+      }
+    var = wave_sum(var);
+    rstd = rsqrtf(var / (float)D + 1e-6f);
+  }
+  const int b = row / ntok;
+  const float* sh = shift ? shift + (int64_t)b * mod_bstride + lane * 4 : nullptr;
+  const float* sc = scale ? scale + (int64_t)b * mod_bstride + lane * 4 : nullptr;
+  bf16_t* yr = y + (int64_t)row * D + lane * 4;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c < nch) {
+      float4 t = v[c];
+      t.x = (t.x - mu) * rstd; t.y = (t.y - mu) * rstd; t.z = (t.z - mu) * rstd; t.w = (t.w - mu) * rstd;
+      if (mode == 0 && w) {
+        const float4 ww = *(const float4*)(w + c * 256 + lane * 4);
+        t.x *= ww.x; t.y *= ww.y; t.z *= ww.z; t.w *= ww.w;
+      }
+      if (sc) {
+        const float4 a = *(const float4*)(sc + c * 256);
+        const float4 s = *(const float4*)(sh + c * 256);
+        t.x = t.x * (1.f + a.x) + s.x; t.y = t.y * (1.f + a.y) + s.y;
+        t.z = t.z * (1.f + a.z) + s.z; t.w = t.w * (1.f + a.w) + s.w;
+      }
+      *(uint2*)(yr + c * 256) = pack4_e(t.x, t.y, t.z, t.w);
+    }
+  }
+}
+
+hipError_t launch_norm_modulate(const float* x, const float* w, const float* shift, const float* scale,
+                                int64_t mod_bstride, bf16_t* y, int M, int D, int ntok, int mode, hipStream_t s) {
+  if (D % 256 != 0 || D > 2048 || M <= 0 || ntok <= 0) return hipErrorInvalidValue;
+  if ((shift == nullptr) != (scale == nullptr)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(norm_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, shift, scale, mod_bstride, y, M,
+                     D, ntok, mode);
+  return hipGetLastError();
+}
+
+// ---- patchify: [B, C, T] fp32 (T contiguous) -> A[(b,tok)][c*4+p] bf16 ----------------------------------
+// Restates pad + cat([x_t, x_cond], 1) + reshape/permute (jat_audiosr_v3.py:435-444, 242-244) without
+// materialising any of them: reads are 16 B per lane along T, the transpose goes through LDS, writes are
+// 256-B runs along the feature dimension.  Tile = 64 tokens x 32 channels.
+__global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ x_t, const float* __restrict__ x_c,
+                                                       bf16_t* __restrict__ A, int B_src, int cond_zero_from, int C_t,
+                                                       int C_c, int T_orig, int ntok) {
+  constexpr int ROW = 264;  // 32 channels x 8 B + 8 B pad: conflict-free ds_write_b64 down a column
+  __shared__ __attribute__((aligned(16))) char tile[64 * ROW];
+  const int tid = threadIdx.x;
+  const int tok0 = blockIdx.x * 64, c0 = blockIdx.y * 32, b = blockIdx.z;
+  const int Ktot = (C_t + C_c) * 4;
+  const float* src;
+  bool zero = false;
+  int cl;
+  if (c0 < C_t) {
+    src = x_t + (int64_t)(b % B_src) * C_t * T_orig;
+    cl = c0;
+  } else {
+    zero = b >= cond_zero_from;
+    src = x_c + (int64_t)b * C_c * T_orig;
+    cl = c0 - C_t;
+  }
+  const int tl = tid & 63, tok = tok0 + tl;
+  const bool aligned = (T_orig & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = (tid >> 6) + 4 * j;
+    float4 v = float4{0.f, 0.f, 0.f, 0.f};
+    if (!zero && tok < ntok) {
+      const float* p = src + (int64_t)(cl + ci) * T_orig + tok * 4;
+      if (aligned) {
+        v = *(const float4*)p;
+      } else {
+        const int t0 = tok * 4;
+        if (t0 + 0 < T_orig) v.x = p[0];
+        if (t0 + 1 < T_orig) v.y = p[1];
+        if (t0 + 2 < T_orig) v.z = p[2];
+        if (t0 + 3 < T_orig) v.w = p[3];
+      }
+    }
+    *(uint2*)(tile + tl * ROW + ci * 8) = pack4_e(v.x, v.y, v.z, v.w);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int id = tid + 256 * j, r = id >> 5, part = id & 31;
+    if (tok0 + r < ntok) {
+      const uint2 v = *(const uint2*)(tile + r * ROW + part * 8);
+      *(uint2*)(A + ((int64_t)b * ntok + tok0 + r) * Ktot + (int64_t)c0 * 4 + part * 4) = v;
+    }
+  }
+}
+
+hipError_t launch_patchify(const float* x_t, const float* x_cond, bf16_t* A, int B, int B_src, int cond_zero_from,
+                           int C_t, int C_c, int T_orig, int ntok, hipStream_t s) {
+  if (C_t % 32 != 0 || C_c % 32 != 0 || B <= 0 || B_src <= 0) return hipErrorInvalidValue;
+  dim3 grid((ntok + 63) / 64, (C_t + C_c) / 32, B);
+  hipLaunchKernelGGL(patchify_kernel, grid, dim3(256), 0, s, x_t, x_cond, A, B_src, cond_zero_from, C_t, C_c, T_orig,
+                     ntok);
+  return hipGetLastError();
+}
+
+// ---- time embedding sinusoid (jat_audiosr_v3.py:194-207) ---------------------------------------------
+__global__ void time_sinusoid_kernel(const float* __restrict__ t, float* __restrict__ e, int B, int D) {
+  const int half = D >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float c = logf(10000.0f) / (float)(half - 1);
+  const float f = expf((float)k * -c);
+  const float a = t[b] * f;
+  e[(int64_t)b * D + k] = sinf(a);
+  e[(int64_t)b * D + half + k] = cosf(a);
+}
+hipError_t launch_time_sinusoid(const float* t, float* e, int B, int D, hipStream_t s) {
+  const int n = B * (D / 2);
+  hipLaunchKernelGGL(time_sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, e, B, D);
+  return hipGetLastError();
+}
+
+// ---- small fp32 linear (t_embedder, jat_audiosr_v3.py:364-369): one wave per output feature -------------
+__global__ void __launch_bounds__(256) linear_f32_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         bf16_t* __restrict__ out_silu, int B, int N, int K,
+                                                         int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int nch = K >> 8;
+  float4 w[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < nch) w[c] = *(const float4*)(W + (int64_t)n * K + c * 256 + lane * 4);
+  const float bn = bias ? bias[n] : 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* xr = in + (int64_t)b * K + lane * 4;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nch) {
+        const float4 xv = *(const float4*)(xr + c * 256);
+        acc += xv.x * w[c].x + xv.y * w[c].y + xv.z * w[c].z + xv.w * w[c].w;
+      }
+    acc = wave_sum(acc) + bn;
+    if (act_out == 1) acc = silu_f(acc);
+    if (lane == 0) {
+      out[(int64_t)b * N + n] = acc;
+      if (out_silu) out_silu[(int64_t)b * N + n] = f2bf_e(silu_f(acc));
+    }
+  }
+}
+hipError_t launch_linear_f32(const float* in, const float* W, const float* bias, float* out, bf16_t* out_silu_bf16,
+                             int B, int N, int K, int act_out, hipStream_t s) {
+  if (K % 256 != 0 || K > 2048) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, s, in, W, bias, out, out_silu_bf16, B, N, K,
+                     act_out);
+  return hipGetLastError();
+}
+
+// ---- casts -------------------------------------------------------------------------------------------
+__global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n, int silu) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 v = *(const float4*)(in + i);
+    if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    *(uint2*)(out + i) = pack4_e(v.x, v.y, v.z, v.w);
+  } else {
+    for (int64_t j = i; j < n; ++j) out[j] = f2bf_e(silu ? silu_f(in[j]) : in[j]);
+  }
+}
+hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, in, out, n, 0);
+  return hipGetLastError();
+}
+hipError_t launch_silu_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, in, out, n, 1);
+  return hipGetLastError();
+}
+
+// ---- CFG combine + Euler step (infer_test_v3m2.py:161-179) ----------------------------------------------
+// x = u + s (c - u);  z += (x - z) / (1 - t + 1e-5) * dt   (t < 0.999)   |   z = x   (otherwise)
+// The branch depends only on the host-side schedule, so it is a kernel argument, not a device read.
+__global__ void __launch_bounds__(256) cfg_euler_kernel(const float* __restrict__ xp, float* __restrict__ z,
+                                                        float cfg_scale, float denom, float dt, int use_cfg,
+                                                        int direct, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      float4 c = *(const float4*)(xp + i);
+      if (use_cfg) {
+        const float4 u = *(const float4*)(xp + n + i);
+        c.x = u.x + cfg_scale * (c.x - u.x); c.y = u.y + cfg_scale * (c.y - u.y);
+        c.z = u.z + cfg_scale * (c.z - u.z); c.w = u.w + cfg_scale * (c.w - u.w);
+      }
+      if (!direct) {
+        const float4 zz = *(const float4*)(z + i);
+        c.x = zz.x + __fdiv_rn(c.x - zz.x, denom) * dt; c.y = zz.y + __fdiv_rn(c.y - zz.y, denom) * dt;
+        c.z = zz.z + __fdiv_rn(c.z - zz.z, denom) * dt; c.w = zz.w + __fdiv_rn(c.w - zz.w, denom) * dt;
+      }
+      *(float4*)(z + i) = c;
+    } else {
+      for (int64_t j = i; j < n; ++j) {
+        float c = xp[j];
+        if (use_cfg) { const float u = xp[n + j]; c = u + cfg_scale * (c - u); }
+        if (!direct) c = z[j] + __fdiv_rn(c - z[j], denom) * dt;
+        z[j] = c;
+      }
+    }
+  }
+}
+hipError_t launch_cfg_euler(const float* xp, float* z, float cfg_scale, float t, float dt, int use_cfg,
+                            int64_t n_per_half, hipStream_t s) {
+  const int direct = !(t < 0.999f);
+  const float denom = 1.0f - t + 1e-5f;
+  int64_t blocks = (n_per_half / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xp, z, cfg_scale, denom, dt, use_cfg,
+                     direct, n_per_half);
+  return hipGetLastError();
+}
+
+// ---- per-channel (de)normalisation (infer_test_v3m2.py:381-382, 394) -------------------------------------
+__global__ void channel_affine_kernel(const float* __restrict__ in, const float* __restrict__ mean,
+                                      const float* __restrict__ sd, float* __restrict__ out, int C, int T,
+                                      int inverse, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)((i / T) % C);
+  out[i] = inverse ? in[i] * sd[c] + mean[c] : (in[i] - mean[c]) / sd[c];
+}
+hipError_t launch_channel_affine(const float* in, const float* mean, const float* std, float* out, int B, int C, int T,
+                                 int inverse, hipStream_t s) {
+  const int64_t n = (int64_t)B * C * T;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(channel_affine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, mean, std, out, C,
+                     T, inverse, n);
+  return hipGetLastError();
+}
+
+// ---- linear crossfade of two chunks (infer_test_v3m2.py:188-233) -----------------------------------------
+// out[r, :Tp-ov] = prev ; out[r, Tp-ov:Tp] = prev*fade_out + cur*fade_in ; out[r, Tp:] = cur[r, ov:]
+// fade_out = linspace(1,0,ov), fade_in = linspace(0,1,ov) evaluated as torch.linspace does (two halves).
+__device__ __forceinline__ float linspace_at(float a, float b, int n, int i) {
+  if (n == 1) return a;
+  const float step = (b - a) / (float)(n - 1);
+  return i < n / 2 ? fmaf(step, (float)i, a) : fmaf(-step, (float)(n - 1 - i), b);
+}
+__global__ void crossfade_pair_kernel(const float* __restrict__ prev, int Tp, const float* __restrict__ cur, int Tc,
+                                      int ov, float* __restrict__ out, int rows) {
+  const int To = Tp + Tc - ov;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * To) return;
+  const int r = (int)(i / To), t = (int)(i - (int64_t)r * To);
+  float v;
+  if (t < Tp - ov) {
+    v = prev[(int64_t)r * Tp + t];
+  } else if (t < Tp) {
+    const int k = t - (Tp - ov);
+    v = prev[(int64_t)r * Tp + t] * linspace_at(1.f, 0.f, ov, k) + cur[(int64_t)r * Tc + k] * linspace_at(0.f, 1.f, ov, k);
+  } else {
+    v = cur[(int64_t)r * Tc + (t - Tp + ov)];
+  }
+  out[i] = v;
+}
+hipError_t launch_crossfade_pair(const float* prev, int Tp, const float* cur, int Tc, int overlap, float* out, int rows,
+                                 hipStream_t s) {
+  if (overlap < 0 || overlap > Tp || overlap > Tc) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)rows * (Tp + Tc - overlap);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(crossfade_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prev, Tp, cur, Tc,
+                     overlap, out, rows);
+  return hipGetLastError();
+}

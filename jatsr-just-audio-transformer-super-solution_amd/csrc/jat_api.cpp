@@ -1,0 +1,636 @@
+// C-ABI host side of libjat_hip.so (declarations and contracts: include/jat_hip.h).
+// Owns the packed weights, lays out the caller's workspace, sequences the gfx950 kernels of one DiT forward
+// on the caller's stream, and captures the 50-step CFG sampler into a hipGraph.  No arithmetic happens here.
+#include "../../include/jat_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "jat_kernels.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) return fail(JAT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                       __FILE__, __LINE__);                                            \
+  } while (0)
+#define JCHK(expr)            \
+  do {                        \
+    int r__ = (expr);         \
+    if (r__ != JAT_OK) return r__; \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static constexpr int MAX_LEN = 2048;  // jat_audiosr_v3.py:361
+static constexpr int HEAD_DIM = 64;
+
+struct LayerW {
+  bf16_t *wqkv, *wo, *w1, *w2;  // [D+2kvD, D], [D, D], [mlp, D], [D, mlp]
+  float *norm1, *norm2, *b1, *b2;
+};
+
+struct jat_model {
+  jat_config cfg;
+  int D, depth, Hq, Hkv, kvD, mlp, bott, Cin, Cc, P, Kp, Fout;
+  bool loaded = false;
+  char* blob = nullptr;  // one device allocation holding every packed tensor
+  size_t blob_bytes = 0;
+  bf16_t *pe_w1, *pe_w2, *wada, *wfinal;
+  float *pe_b1, *pe_b2, *te_w1, *te_b1, *te_w2, *te_b2, *bada, *final_norm, *bfinal, *rope_cos, *rope_sin;
+  std::vector<LayerW> layers;
+  int gemm_variant = 0;
+};
+
+// workspace carve-up for a forward over `B` batch rows of `ntok` tokens
+struct Workspace {
+  bf16_t *a_patch, *h_patch, *xn, *q, *k, *vt, *ao, *hm, *t_silu;
+  float *x, *mod, *e_sin, *t_h, *t_emb;
+  int npad;
+  size_t vt_bytes, total;
+};
+
+static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
+  Workspace w;
+  size_t off = 0;
+  const size_t M = (size_t)B * ntok;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  w.npad = (int)align_up((size_t)ntok, 64);
+  w.a_patch = (bf16_t*)take(M * m->Kp * 2);
+  w.h_patch = (bf16_t*)take(M * m->bott * 2);
+  w.x = (float*)take(M * m->D * 4);
+  w.xn = (bf16_t*)take(M * m->D * 2);
+  w.q = (bf16_t*)take(M * m->D * 2);
+  w.k = (bf16_t*)take(M * m->kvD * 2);
+  w.vt_bytes = (size_t)B * m->Hkv * HEAD_DIM * w.npad * 2;
+  w.vt = (bf16_t*)take(w.vt_bytes);
+  w.ao = (bf16_t*)take(M * m->D * 2);
+  w.hm = (bf16_t*)take(M * m->mlp * 2);
+  w.mod = (float*)take((size_t)B * m->depth * 6 * m->D * 4);
+  w.e_sin = (float*)take((size_t)B * m->D * 4);
+  w.t_h = (float*)take((size_t)B * m->D * 4);
+  w.t_emb = (float*)take((size_t)B * m->D * 4);
+  w.t_silu = (bf16_t*)take((size_t)B * m->D * 2);
+  w.total = off;
+  return w;
+}
+
+extern "C" const char* jat_last_error(void) { return g_err; }
+extern "C" int jat_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int jat_model_create(const jat_config* c, jat_model** out) {
+  if (!c || !out) return fail(JAT_E_INVALID, "null argument");
+  // same checks as the reference constructor asserts (jat_audiosr_v3.py:119-120) plus kernel limits
+  if (c->num_q_heads <= 0 || c->hidden_size % c->num_q_heads != 0)
+    return fail(JAT_E_INVALID, "hidden_size must be divisible by num_q_heads");
+  if (c->num_kv_heads <= 0 || c->num_q_heads % c->num_kv_heads != 0)
+    return fail(JAT_E_INVALID, "num_q_heads must be divisible by num_kv_heads");
+  if (c->hidden_size / c->num_q_heads != HEAD_DIM) return fail(JAT_E_INVALID, "head_dim must be 64");
+  if (c->patch_len != 4) return fail(JAT_E_INVALID, "patch_len must be 4");
+  if (c->hidden_size % 256 != 0 || c->hidden_size > 2048)
+    return fail(JAT_E_INVALID, "hidden_size must be a multiple of 256, <= 2048");
+  if (c->bottleneck_dim % 128 != 0 || c->mlp_hidden % 128 != 0)
+    return fail(JAT_E_INVALID, "bottleneck_dim and mlp_hidden must be multiples of 128");
+  if (c->input_channels % 32 != 0 || c->cond_channels % 32 != 0 || c->input_channels <= 0 || c->cond_channels <= 0)
+    return fail(JAT_E_INVALID, "channel counts must be positive multiples of 32");
+  if (c->depth <= 0) return fail(JAT_E_INVALID, "depth must be positive");
+  if (c->norm_mode != JAT_NORM_RMS_W && c->norm_mode != JAT_NORM_LN_NOAFFINE)
+    return fail(JAT_E_INVALID, "unknown norm_mode");
+  jat_model* m = new jat_model();
+  m->cfg = *c;
+  m->D = c->hidden_size; m->depth = c->depth; m->Hq = c->num_q_heads; m->Hkv = c->num_kv_heads;
+  m->kvD = m->Hkv * HEAD_DIM; m->mlp = c->mlp_hidden; m->bott = c->bottleneck_dim;
+  m->Cin = c->input_channels; m->Cc = c->cond_channels; m->P = 4;
+  m->Kp = m->P * (m->Cin + m->Cc); m->Fout = m->P * m->Cin;
+  if (const char* v = getenv("JAT_GEMM_VARIANT")) m->gemm_variant = atoi(v);
+  *out = m;
+  return JAT_OK;
+}
+
+extern "C" void jat_model_destroy(jat_model* m) {
+  if (!m) return;
+  if (m->blob) (void)hipFree(m->blob);
+  delete m;
+}
+
+extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, void* stream_) {
+  if (!m || !named) return fail(JAT_E_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)stream_;
+  std::unordered_map<std::string, const jat_tensor_ref*> by_name;
+  for (int i = 0; i < n; ++i) by_name[named[i].name] = &named[i];
+  const int D = m->D, kvD = m->kvD, mlp = m->mlp, bott = m->bott, depth = m->depth;
+  const bool rms = m->cfg.norm_mode == JAT_NORM_RMS_W;
+
+  // ---- layout of the packed blob ----
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  const size_t o_pe_w1 = take((size_t)bott * m->Kp * 2), o_pe_w2 = take((size_t)D * bott * 2);
+  const size_t o_wada = take((size_t)depth * 6 * D * D * 2), o_wfinal = take((size_t)m->Fout * D * 2);
+  std::vector<size_t> o_qkv(depth), o_wo(depth), o_w1(depth), o_w2(depth), o_n1(depth), o_n2(depth), o_b1(depth),
+      o_b2(depth);
+  for (int l = 0; l < depth; ++l) {
+    o_qkv[l] = take((size_t)(D + 2 * kvD) * D * 2); o_wo[l] = take((size_t)D * D * 2);
+    o_w1[l] = take((size_t)mlp * D * 2); o_w2[l] = take((size_t)D * mlp * 2);
+    o_n1[l] = take((size_t)D * 4); o_n2[l] = take((size_t)D * 4);
+    o_b1[l] = take((size_t)mlp * 4); o_b2[l] = take((size_t)D * 4);
+  }
+  const size_t o_pe_b1 = take((size_t)bott * 4), o_pe_b2 = take((size_t)D * 4);
+  const size_t o_te_w1 = take((size_t)D * D * 4), o_te_b1 = take((size_t)D * 4);
+  const size_t o_te_w2 = take((size_t)D * D * 4), o_te_b2 = take((size_t)D * 4);
+  const size_t o_bada = take((size_t)depth * 6 * D * 4), o_fn = take((size_t)D * 4), o_bfinal = take((size_t)m->Fout * 4);
+  const size_t o_cos = take((size_t)MAX_LEN * 32 * 4), o_sin = take((size_t)MAX_LEN * 32 * 4);
+  if (!m->blob) {
+    HIPCHK(hipMalloc((void**)&m->blob, off));
+    m->blob_bytes = off;
+  }
+  char* base = m->blob;
+  m->pe_w1 = (bf16_t*)(base + o_pe_w1); m->pe_w2 = (bf16_t*)(base + o_pe_w2);
+  m->wada = (bf16_t*)(base + o_wada); m->wfinal = (bf16_t*)(base + o_wfinal);
+  m->pe_b1 = (float*)(base + o_pe_b1); m->pe_b2 = (float*)(base + o_pe_b2);
+  m->te_w1 = (float*)(base + o_te_w1); m->te_b1 = (float*)(base + o_te_b1);
+  m->te_w2 = (float*)(base + o_te_w2); m->te_b2 = (float*)(base + o_te_b2);
+  m->bada = (float*)(base + o_bada); m->final_norm = (float*)(base + o_fn); m->bfinal = (float*)(base + o_bfinal);
+  m->rope_cos = (float*)(base + o_cos); m->rope_sin = (float*)(base + o_sin);
+  m->layers.resize(depth);
+  for (int l = 0; l < depth; ++l) {
+    LayerW& L = m->layers[l];
+    L.wqkv = (bf16_t*)(base + o_qkv[l]); L.wo = (bf16_t*)(base + o_wo[l]);
+    L.w1 = (bf16_t*)(base + o_w1[l]); L.w2 = (bf16_t*)(base + o_w2[l]);
+    L.norm1 = (float*)(base + o_n1[l]); L.norm2 = (float*)(base + o_n2[l]);
+    L.b1 = (float*)(base + o_b1[l]); L.b2 = (float*)(base + o_b2[l]);
+  }
+
+  // ---- copy / convert ----
+  int rc = JAT_OK;
+  auto find = [&](const std::string& name, int64_t numel) -> const float* {
+    auto it = by_name.find(name);
+    if (it == by_name.end()) { rc = fail(JAT_E_STATE, "missing parameter '%s'", name.c_str()); return nullptr; }
+    if (it->second->numel != numel) {
+      rc = fail(JAT_E_INVALID, "parameter '%s' has %lld elements, expected %lld", name.c_str(),
+                (long long)it->second->numel, (long long)numel);
+      return nullptr;
+    }
+    return it->second->data;
+  };
+  auto to_bf16 = [&](const std::string& name, bf16_t* dst, int64_t numel) {
+    const float* src = find(name, numel);
+    if (!src) return;
+    if (launch_cast_bf16(src, dst, numel, s) != hipSuccess) rc = fail(JAT_E_HIP, "cast kernel launch failed");
+  };
+  auto to_f32 = [&](const std::string& name, float* dst, int64_t numel) {
+    const float* src = find(name, numel);
+    if (!src) return;
+    if (hipMemcpyAsync(dst, src, numel * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      rc = fail(JAT_E_HIP, "memcpy failed for '%s'", name.c_str());
+  };
+  auto ones = [&](float* dst, int64_t numel) {
+    std::vector<float> h(numel, 1.0f);
+    if (hipMemcpyAsync(dst, h.data(), numel * 4, hipMemcpyHostToDevice, s) != hipSuccess) rc = fail(JAT_E_HIP, "memcpy");
+    (void)hipStreamSynchronize(s);
+  };
+  to_bf16("patch_embed.proj.0.weight", m->pe_w1, (int64_t)bott * m->Kp);
+  to_f32("patch_embed.proj.0.bias", m->pe_b1, bott);
+  to_bf16("patch_embed.proj.2.weight", m->pe_w2, (int64_t)D * bott);
+  to_f32("patch_embed.proj.2.bias", m->pe_b2, D);
+  to_f32("t_embedder.1.weight", m->te_w1, (int64_t)D * D);
+  to_f32("t_embedder.1.bias", m->te_b1, D);
+  to_f32("t_embedder.3.weight", m->te_w2, (int64_t)D * D);
+  to_f32("t_embedder.3.bias", m->te_b2, D);
+  for (int l = 0; l < depth && rc == JAT_OK; ++l) {
+    const std::string p = "blocks." + std::to_string(l) + ".";
+    LayerW& L = m->layers[l];
+    if (rms) { to_f32(p + "norm1.weight", L.norm1, D); to_f32(p + "norm2.weight", L.norm2, D); }
+    else { ones(L.norm1, D); ones(L.norm2, D); }
+    to_bf16(p + "attn.q_proj.weight", L.wqkv, (int64_t)D * D);                       // fused [Wq; Wk; Wv]
+    to_bf16(p + "attn.k_proj.weight", L.wqkv + (int64_t)D * D, (int64_t)kvD * D);
+    to_bf16(p + "attn.v_proj.weight", L.wqkv + (int64_t)(D + kvD) * D, (int64_t)kvD * D);
+    to_bf16(p + "attn.out_proj.weight", L.wo, (int64_t)D * D);
+    to_bf16(p + "mlp.0.weight", L.w1, (int64_t)mlp * D);
+    to_f32(p + "mlp.0.bias", L.b1, mlp);
+    to_bf16(p + "mlp.3.weight", L.w2, (int64_t)D * mlp);
+    to_f32(p + "mlp.3.bias", L.b2, D);
+    to_bf16(p + "adaLN_modulation.1.weight", m->wada + (int64_t)l * 6 * D * D, (int64_t)6 * D * D);
+    to_f32(p + "adaLN_modulation.1.bias", m->bada + (int64_t)l * 6 * D, (int64_t)6 * D);
+  }
+  if (rms) to_f32("final_layer.0.weight", m->final_norm, D); else ones(m->final_norm, D);
+  to_bf16("final_layer.1.weight", m->wfinal, (int64_t)m->Fout * D);
+  to_f32("final_layer.1.bias", m->bfinal, m->Fout);
+  if (rc != JAT_OK) return rc;
+
+  // RoPE tables in fp32 exactly as RoPE.__init__ builds them (jat_audiosr_v3.py:77-85); only the first half
+  // of `emb = cat([freqs, freqs])` is distinct.
+  {
+    std::vector<float> hc((size_t)MAX_LEN * 32), hs((size_t)MAX_LEN * 32);
+    for (int i = 0; i < 32; ++i) {
+      const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+      for (int pos = 0; pos < MAX_LEN; ++pos) {
+        const float a = (float)pos * inv_freq;
+        hc[(size_t)pos * 32 + i] = cosf(a);
+        hs[(size_t)pos * 32 + i] = sinf(a);
+      }
+    }
+    HIPCHK(hipMemcpyAsync(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  m->loaded = true;
+  return JAT_OK;
+}
+
+extern "C" int jat_model_workspace_bytes(const jat_model* m, int32_t B, int32_t T, size_t* out) {
+  if (!m || !out || B <= 0 || T <= 0) return fail(JAT_E_INVALID, "bad argument");
+  const int ntok = (T + 3) / 4;
+  *out = carve(m, B, ntok, nullptr).total;
+  return JAT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward pieces
+// ---------------------------------------------------------------------------------------------------------
+static int gemm(const jat_model* m, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, int M, int N, int K,
+                int epi, GemmArgs extra, hipStream_t s) {
+  GemmArgs a = extra;
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
+  int variant = m->gemm_variant;
+  hipError_t e = launch_gemm(a, epi, variant, s);
+  if (e != hipSuccess) return fail(JAT_E_HIP, "gemm launch (M=%d N=%d K=%d epi=%d): %s", M, N, K, epi, hipGetErrorString(e));
+  return JAT_OK;
+}
+#define KCHK(expr)                                                                            \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) return fail(JAT_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));   \
+  } while (0)
+
+// t [B] -> t_emb [B,D] fp32 (+ bf16 silu(t_emb))  (t_embedder, jat_audiosr_v3.py:364-369)
+static int time_path(const jat_model* m, const Workspace& w, const float* t, int B, hipStream_t s) {
+  KCHK(launch_time_sinusoid(t, w.e_sin, B, m->D, s));
+  KCHK(launch_linear_f32(w.e_sin, m->te_w1, m->te_b1, w.t_h, nullptr, B, m->D, m->D, 1, s));
+  KCHK(launch_linear_f32(w.t_h, m->te_w2, m->te_b2, w.t_emb, w.t_silu, B, m->D, m->D, 0, s));
+  return JAT_OK;
+}
+// silu(t_emb) bf16 [B,D] -> mod [B, nlayers*6D] for layers [l0, l0+nl)  (adaLN_modulation, :275-278)
+static int adaln_path(const jat_model* m, const bf16_t* t_silu, float* mod, int B, int l0, int nl, hipStream_t s) {
+  GemmArgs e{};
+  e.out = mod; e.ldo = (int64_t)nl * 6 * m->D; e.bias = m->bada + (int64_t)l0 * 6 * m->D; e.ntok = 1;
+  return gemm(m, t_silu, m->D, m->wada + (int64_t)l0 * 6 * m->D * m->D, m->D, B, nl * 6 * m->D, m->D, EPI_F32, e, s);
+}
+
+// one DiTBlock_GQA on the residual stream w.x  (jat_audiosr_v3.py:284-308); mod_l = this layer's 6D row of batch 0
+static int run_block(const jat_model* m, const Workspace& w, int l, int B, int ntok, const float* mod_l,
+                     int64_t bstride, hipStream_t s) {
+  const int D = m->D, M = B * ntok;
+  const LayerW& L = m->layers[l];
+  KCHK(launch_norm_modulate(w.x, L.norm1, mod_l + 0 * D, mod_l + 1 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  {
+    GemmArgs e{};
+    e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = ntok;
+    e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
+    JCHK(gemm(m, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
+  }
+  {
+    AttnArgs a{};
+    a.q = w.q; a.k = w.k; a.vt = w.vt; a.o = w.ao; a.ldq = D; a.ldk = m->kvD; a.ldo = D;
+    a.B = B; a.N = ntok; a.Hq = m->Hq; a.Hkv = m->Hkv; a.npad = w.npad;
+    a.scale_log2e = 0.125f * 1.4426950408889634f;
+    KCHK(launch_attention(a, s));
+  }
+  {
+    GemmArgs e{};
+    e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
+    JCHK(gemm(m, w.ao, D, L.wo, D, M, D, D, EPI_RESID, e, s));
+  }
+  KCHK(launch_norm_modulate(w.x, L.norm2, mod_l + 3 * D, mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  {
+    GemmArgs e{};
+    e.out = w.hm; e.ldo = m->mlp; e.bias = L.b1; e.ntok = ntok;
+    JCHK(gemm(m, w.xn, D, L.w1, D, M, m->mlp, D, EPI_BF16_GELU, e, s));
+  }
+  {
+    GemmArgs e{};
+    e.out = w.x; e.ldo = D; e.bias = L.b2; e.gate = mod_l + 5 * D; e.gate_bstride = bstride; e.ntok = ntok;
+    JCHK(gemm(m, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_RESID, e, s));
+  }
+  return JAT_OK;
+}
+
+// Whole forward over B batch rows.  x_t rows are read modulo B_src and the condition is zero from batch row
+// cond_zero_from on: this is how the CFG double batch [z;z],[lr;0] (infer_test_v3m2.py:154-156) is fed
+// without materialising the concatenations.  mod == nullptr: compute the modulation from t [B].
+static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t, int B_src, const float* x_cond,
+                        int cond_zero_from, const float* t, const float* mod, int64_t mod_bstride, float* x_pred,
+                        int B, int T, hipStream_t s) {
+  const int ntok = (T + 3) / 4, M = B * ntok, D = m->D;
+  if (!mod) {
+    JCHK(time_path(m, w, t, B, s));
+    JCHK(adaln_path(m, w.t_silu, w.mod, B, 0, m->depth, s));
+    mod = w.mod;
+    mod_bstride = (int64_t)m->depth * 6 * D;
+  }
+  HIPCHK(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));  // zero the key padding of V^T once per forward
+  KCHK(launch_patchify(x_t, x_cond, w.a_patch, B, B_src, cond_zero_from, m->Cin, m->Cc, T, ntok, s));
+  {
+    GemmArgs e{};
+    e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok;
+    JCHK(gemm(m, w.a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16_GELU, e, s));
+  }
+  {
+    GemmArgs e{};
+    e.out = w.x; e.ldo = D; e.bias = m->pe_b2; e.ntok = ntok;
+    JCHK(gemm(m, w.h_patch, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, e, s));
+  }
+  for (int l = 0; l < m->depth; ++l) JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s));
+  KCHK(launch_norm_modulate(w.x, m->final_norm, nullptr, nullptr, 0, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  {
+    GemmArgs e{};
+    e.out = x_pred; e.bias = m->bfinal; e.ntok = ntok; e.C_out = m->Cin; e.T_orig = T;
+    JCHK(gemm(m, w.xn, D, m->wfinal, D, M, m->Fout, D, EPI_UNPATCH, e, s));
+  }
+  return JAT_OK;
+}
+
+static int check_ready(const jat_model* m, int B, int ntok, void* ws, size_t ws_bytes, Workspace* w) {
+  if (!m) return fail(JAT_E_INVALID, "null model");
+  if (!m->loaded) return fail(JAT_E_STATE, "weights not loaded");
+  if (B <= 0 || ntok <= 0) return fail(JAT_E_INVALID, "B and T must be positive");
+  if (ntok > MAX_LEN) return fail(JAT_E_SEQLEN, "Sequence length %d exceeds max_len %d", ntok, MAX_LEN);
+  *w = carve(m, B, ntok, (char*)ws);
+  if (!ws || ws_bytes < w->total)
+    return fail(JAT_E_STATE, "workspace too small: %zu < %zu bytes", ws_bytes, w->total);
+  return JAT_OK;
+}
+
+extern "C" int jat_forward(jat_model* m, const float* x_t, const float* t, const float* x_cond, float* x_pred,
+                           int32_t B, int32_t T, void* ws, size_t ws_bytes, void* stream) {
+  if (T <= 0) return fail(JAT_E_INVALID, "T must be positive");
+  Workspace w;
+  JCHK(check_ready(m, B, (T + 3) / 4, ws, ws_bytes, &w));
+  return forward_impl(m, w, x_t, B, x_cond, B, t, nullptr, 0, x_pred, B, T, (hipStream_t)stream);
+}
+
+extern "C" int jat_time_embed(jat_model* m, const float* t, float* t_emb, int32_t B, void* ws, size_t ws_bytes,
+                              void* stream) {
+  Workspace w;
+  JCHK(check_ready(m, B, 1, ws, ws_bytes, &w));
+  hipStream_t s = (hipStream_t)stream;
+  JCHK(time_path(m, w, t, B, s));
+  HIPCHK(hipMemcpyAsync(t_emb, w.t_emb, (size_t)B * m->D * 4, hipMemcpyDeviceToDevice, s));
+  return JAT_OK;
+}
+
+extern "C" int jat_block_forward(jat_model* m, int32_t layer, const float* x, const float* t_emb, float* y, int32_t B,
+                                 int32_t N, void* ws, size_t ws_bytes, void* stream) {
+  Workspace w;
+  JCHK(check_ready(m, B, N, ws, ws_bytes, &w));
+  if (layer < 0 || layer >= m->depth) return fail(JAT_E_INVALID, "layer out of range");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t xb = (size_t)B * N * m->D * 4;
+  KCHK(launch_silu_bf16(t_emb, w.t_silu, (int64_t)B * m->D, s));
+  JCHK(adaln_path(m, w.t_silu, w.mod, B, layer, 1, s));
+  HIPCHK(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
+  HIPCHK(hipMemcpyAsync(w.x, x, xb, hipMemcpyDeviceToDevice, s));
+  JCHK(run_block(m, w, layer, B, N, w.mod, (int64_t)6 * m->D, s));
+  HIPCHK(hipMemcpyAsync(y, w.x, xb, hipMemcpyDeviceToDevice, s));
+  return JAT_OK;
+}
+
+extern "C" int jat_attn_forward(jat_model* m, int32_t layer, const float* x, float* y, int32_t B, int32_t N, void* ws,
+                                size_t ws_bytes, void* stream) {
+  Workspace w;
+  JCHK(check_ready(m, B, N, ws, ws_bytes, &w));
+  if (layer < 0 || layer >= m->depth) return fail(JAT_E_INVALID, "layer out of range");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->D, M = B * N;
+  const LayerW& L = m->layers[layer];
+  HIPCHK(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
+  KCHK(launch_norm_modulate(x, nullptr, nullptr, nullptr, 0, w.xn, M, D, N, 2, s));  // plain bf16 cast
+  {
+    GemmArgs e{};
+    e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = N;
+    e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
+    JCHK(gemm(m, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
+  }
+  {
+    AttnArgs a{};
+    a.q = w.q; a.k = w.k; a.vt = w.vt; a.o = w.ao; a.ldq = D; a.ldk = m->kvD; a.ldo = D;
+    a.B = B; a.N = N; a.Hq = m->Hq; a.Hkv = m->Hkv; a.npad = w.npad;
+    a.scale_log2e = 0.125f * 1.4426950408889634f;
+    KCHK(launch_attention(a, s));
+  }
+  {
+    GemmArgs e{};
+    e.out = y; e.ldo = D; e.ntok = N;
+    JCHK(gemm(m, w.ao, D, L.wo, D, M, D, D, EPI_F32, e, s));
+  }
+  return JAT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sampler
+// ---------------------------------------------------------------------------------------------------------
+struct jat_sampler {
+  jat_model* m;
+  int B, T, steps, Bf;  // Bf = batch rows per forward (2B with CFG)
+  float cfg_scale;
+  bool use_cfg;
+  std::vector<float> ts;  // [host] linspace(0,1,steps+1)
+  char* blob = nullptr;   // private device allocation
+  float *z, *lr, *xpred, *mod_table, *ts_dev;
+  void* ws;
+  size_t ws_bytes;
+  Workspace w;
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+// torch.linspace(0, 1, n) in fp32 as PyTorch evaluates it (step = fp32(1/(n-1)); first half start+step*i,
+// second half end-step*(n-1-i), one rounding each) — pinned by tests/golden/misc.npz `linspace51`.
+static void linspace01(int n, std::vector<float>& out) {
+  out.resize(n);
+  const float step = 1.0f / (float)(n - 1);
+  for (int i = 0; i < n; ++i)
+    out[i] = i < n / 2 ? (float)((double)step * i) : (float)(1.0 - (double)step * (n - 1 - i));
+}
+
+static int sampler_steps(jat_sampler* sp, hipStream_t s) {
+  jat_model* m = sp->m;
+  const int64_t n_half = (int64_t)sp->B * m->Cin * sp->T;
+  const int64_t row = (int64_t)m->depth * 6 * m->D;
+  for (int i = 0; i < sp->steps; ++i) {
+    const float t_curr = sp->ts[i], dt = sp->ts[i + 1] - sp->ts[i];
+    JCHK(forward_impl(m, sp->w, sp->z, sp->B, sp->lr, sp->B, nullptr, sp->mod_table + i * row, 0, sp->xpred, sp->Bf,
+                      sp->T, s));
+    KCHK(launch_cfg_euler(sp->xpred, sp->z, sp->cfg_scale, t_curr, dt, sp->use_cfg ? 1 : 0, n_half, s));
+  }
+  return JAT_OK;
+}
+
+extern "C" void jat_sampler_destroy(jat_sampler* sp) {
+  if (!sp) return;
+  if (sp->exec) (void)hipGraphExecDestroy(sp->exec);
+  if (sp->graph) (void)hipGraphDestroy(sp->graph);
+  if (sp->cap_stream) (void)hipStreamDestroy(sp->cap_stream);
+  if (sp->blob) (void)hipFree(sp->blob);
+  delete sp;
+}
+
+extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t steps, float cfg_scale,
+                                  jat_sampler** out) {
+  if (!m || !out) return fail(JAT_E_INVALID, "null argument");
+  if (!m->loaded) return fail(JAT_E_STATE, "weights not loaded");
+  if (B <= 0 || T <= 0 || steps <= 0) return fail(JAT_E_INVALID, "B, T, steps must be positive");
+  const int ntok = (T + 3) / 4;
+  if (ntok > MAX_LEN) return fail(JAT_E_SEQLEN, "Sequence length %d exceeds max_len %d", ntok, MAX_LEN);
+  jat_sampler* sp = new jat_sampler();
+  sp->m = m; sp->B = B; sp->T = T; sp->steps = steps; sp->cfg_scale = cfg_scale;
+  sp->use_cfg = cfg_scale != 1.0f;  // infer_test_v3m2.py:139
+  sp->Bf = sp->use_cfg ? 2 * B : B;
+  linspace01(steps + 1, sp->ts);
+
+  const size_t lat = (size_t)B * m->Cin * T * 4;
+  const size_t row = (size_t)m->depth * 6 * m->D;
+  const int Bws = sp->Bf > steps ? sp->Bf : steps;  // the table precompute runs the time path on `steps` rows
+  const size_t ws_bytes = carve(m, Bws, ntok, nullptr).total;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  const size_t o_z = take(lat), o_lr = take(lat), o_xp = take((size_t)sp->Bf * m->Cin * T * 4);
+  const size_t o_tab = take((size_t)steps * row * 4), o_ts = take((size_t)steps * 4), o_ws = take(ws_bytes);
+  hipError_t e = hipMalloc((void**)&sp->blob, off);
+  if (e != hipSuccess) { delete sp; return fail(JAT_E_HIP, "hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
+  sp->z = (float*)(sp->blob + o_z); sp->lr = (float*)(sp->blob + o_lr); sp->xpred = (float*)(sp->blob + o_xp);
+  sp->mod_table = (float*)(sp->blob + o_tab); sp->ts_dev = (float*)(sp->blob + o_ts);
+  sp->ws = sp->blob + o_ws; sp->ws_bytes = ws_bytes;
+
+  int rc = JAT_OK;
+  auto bail = [&](int code) { jat_sampler_destroy(sp); return code; };
+  if (hipStreamCreateWithFlags(&sp->cap_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(JAT_E_HIP, "hipStreamCreate failed"));
+  hipStream_t s = sp->cap_stream;
+
+  // modulation table [steps, depth*6D]: every row of step i shares t = ts[i] (infer_test_v3m2.py:150)
+  {
+    Workspace wt = carve(m, steps, ntok, (char*)sp->ws);
+    if (hipMemcpyAsync(sp->ts_dev, sp->ts.data(), (size_t)steps * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+      return bail(fail(JAT_E_HIP, "memcpy ts"));
+    if ((rc = time_path(m, wt, sp->ts_dev, steps, s)) != JAT_OK) return bail(rc);
+    if ((rc = adaln_path(m, wt.t_silu, sp->mod_table, steps, 0, m->depth, s)) != JAT_OK) return bail(rc);
+    if (hipStreamSynchronize(s) != hipSuccess) return bail(fail(JAT_E_HIP, "sync after table build"));
+  }
+  sp->w = carve(m, sp->Bf, ntok, (char*)sp->ws);
+
+  // one eager pass first: sets every kernel's function attributes outside of capture and validates launches
+  if (hipMemsetAsync(sp->z, 0, lat, s) != hipSuccess || hipMemsetAsync(sp->lr, 0, lat, s) != hipSuccess)
+    return bail(fail(JAT_E_HIP, "memset"));
+  {
+    const int saved = sp->steps;
+    sp->steps = 1;
+    rc = sampler_steps(sp, s);
+    sp->steps = saved;
+    if (rc != JAT_OK) return bail(rc);
+    if (hipStreamSynchronize(s) != hipSuccess)
+      return bail(fail(JAT_E_HIP, "eager warm-up step failed: %s", hipGetErrorString(hipGetLastError())));
+  }
+  // capture all `steps` forwards + Euler updates into one graph
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
+    return bail(fail(JAT_E_HIP, "hipStreamBeginCapture failed"));
+  rc = sampler_steps(sp, s);
+  e = hipStreamEndCapture(s, &sp->graph);
+  if (rc != JAT_OK) return bail(rc);
+  if (e != hipSuccess) return bail(fail(JAT_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)));
+  e = hipGraphInstantiate(&sp->exec, sp->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) return bail(fail(JAT_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)));
+  *out = sp;
+  return JAT_OK;
+}
+
+extern "C" int jat_sampler_run(jat_sampler* sp, const float* lr_latent, const float* z0, float* z_out,
+                               int32_t use_graph, void* stream) {
+  if (!sp || !lr_latent || !z0 || !z_out) return fail(JAT_E_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lat = (size_t)sp->B * sp->m->Cin * sp->T * 4;
+  HIPCHK(hipMemcpyAsync(sp->lr, lr_latent, lat, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(sp->z, z0, lat, hipMemcpyDeviceToDevice, s));
+  if (use_graph) {
+    HIPCHK(hipGraphLaunch(sp->exec, s));
+  } else {
+    JCHK(sampler_steps(sp, s));
+  }
+  HIPCHK(hipMemcpyAsync(z_out, sp->z, lat, hipMemcpyDeviceToDevice, s));
+  return JAT_OK;
+}
+
+extern "C" int jat_cfg_euler_step(const float* x_pred_2B, float* z, float cfg_scale, float t, float dt, int32_t B,
+                                  int32_t C, int32_t T, void* stream) {
+  KCHK(launch_cfg_euler(x_pred_2B, z, cfg_scale, t, dt, cfg_scale != 1.0f ? 1 : 0, (int64_t)B * C * T,
+                        (hipStream_t)stream));
+  return JAT_OK;
+}
+
+extern "C" int jat_channel_affine(const float* in, const float* mean, const float* std, float* out, int32_t B, int32_t C,
+                                  int32_t T, int32_t inverse, void* stream) {
+  KCHK(launch_channel_affine(in, mean, std, out, B, C, T, inverse, (hipStream_t)stream));
+  return JAT_OK;
+}
+extern "C" int jat_crossfade_pair(const float* prev, int32_t Tp, const float* cur, int32_t Tc, int32_t overlap,
+                                  float* out, int32_t rows, void* stream) {
+  KCHK(launch_crossfade_pair(prev, Tp, cur, Tc, overlap, out, rows, (hipStream_t)stream));
+  return JAT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-kernel entry points
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int jat_k_norm_modulate(const float* x, const float* w, const float* shift, const float* scale,
+                                   int64_t mod_bstride, uint16_t* y, int32_t M, int32_t D, int32_t rows_per_batch,
+                                   int32_t norm_mode, void* stream) {
+  KCHK(launch_norm_modulate(x, w, shift, scale, mod_bstride, y, M, D, rows_per_batch, norm_mode, (hipStream_t)stream));
+  return JAT_OK;
+}
+extern "C" int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N,
+                          int32_t K, int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch,
+                          int32_t variant, void* stream) {
+  if (epilogue < 0 || epilogue > EPI_RESID) return fail(JAT_E_INVALID, "epilogue must be 0..3");
+  GemmArgs a{};
+  a.A = A; a.W = W; a.lda = K; a.ldw = K; a.M = M; a.N = N; a.K = K;
+  a.out = C; a.ldo = N; a.bias = bias; a.gate = gate; a.gate_bstride = gate_bstride;
+  a.ntok = rows_per_batch > 0 ? rows_per_batch : 1;
+  KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
+  return JAT_OK;
+}
+extern "C" int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t B,
+                               int32_t N, int32_t Hq, int32_t Hkv, int32_t Npad, void* stream) {
+  AttnArgs a{};
+  a.q = q; a.k = k; a.vt = vt; a.o = o; a.ldq = (int64_t)Hq * 64; a.ldk = (int64_t)Hkv * 64; a.ldo = (int64_t)Hq * 64;
+  a.B = B; a.N = N; a.Hq = Hq; a.Hkv = Hkv; a.npad = Npad;
+  a.scale_log2e = 0.125f * 1.4426950408889634f;
+  KCHK(launch_attention(a, (hipStream_t)stream));
+  return JAT_OK;
+}
+extern "C" int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream) {
+  KCHK(launch_cast_bf16(in, out, n, (hipStream_t)stream));
+  return JAT_OK;
+}

@@ -1,0 +1,79 @@
+// Internal launch interface between the C-ABI host code (jat_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+// ---- GEMM: C[M,N] = A[M,K] * W[N,K]^T with a fused epilogue ------------------------------------
+enum GemmEpi : int {
+  EPI_F32 = 0,       // out fp32 [M,ldo] = acc + bias
+  EPI_BF16 = 1,      // out bf16 [M,ldo] = acc + bias
+  EPI_BF16_GELU = 2, // out bf16 = gelu_erf(acc + bias)        (jat_audiosr_v3.py:221-225, 266-268)
+  EPI_RESID = 3,     // out fp32 [M,ldo] += gate[b,n]*(acc+bias) (jat_audiosr_v3.py:300,306)
+  EPI_QKV_ROPE = 4,  // RoPE on q,k heads; q->[M,D], k->[M,kvD], v->vt[B,Hkv,64,Npad] (:154-160)
+  EPI_UNPATCH = 5,   // out fp32 [B,C,T_orig]: feature c*4+p of token n -> [b,c,4n+p] (:406-420,465-469)
+};
+
+struct GemmArgs {
+  const bf16_t* A;  // [M, lda] bf16, K contiguous
+  const bf16_t* W;  // [N, ldw] bf16, K contiguous (nn.Linear weight layout)
+  int64_t lda, ldw;
+  int M, N, K;
+  // epilogue
+  void* out;
+  int64_t ldo;
+  const float* bias;     // [N] or nullptr
+  const float* gate;     // EPI_RESID: gate + b*gate_bstride + n
+  int64_t gate_bstride;
+  int ntok;              // rows per batch sample (b = m / ntok, pos = m % ntok)
+  // EPI_QKV_ROPE
+  bf16_t* k_out;
+  bf16_t* vt_out;
+  int D, kvD, npad;
+  const float* rope_cos; // [max_pos, 32]
+  const float* rope_sin;
+  // EPI_UNPATCH
+  int C_out, T_orig;
+};
+
+// variant: 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves
+hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);
+int gemm_num_variants();
+
+// ---- attention -----------------------------------------------------------------------------------
+struct AttnArgs {
+  const bf16_t* q;   // [B*N, ldq]   head h at column h*64
+  const bf16_t* k;   // [B*N, ldk]   kv head g at column g*64
+  const bf16_t* vt;  // [B, Hkv, 64, npad]  (V transposed, zero padded for key >= N)
+  bf16_t* o;         // [B*N, ldo]
+  int64_t ldq, ldk, ldo;
+  int B, N, Hq, Hkv, npad;
+  float scale_log2e; // (1/sqrt(64)) * log2(e)
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---- row-wise / elementwise ------------------------------------------------------------------------
+// y = norm(x)*w*(1+scale[b]) + shift[b] -> bf16.  mode: 0 RMS(+w), 1 LayerNorm no affine, 2 none (cast).
+hipError_t launch_norm_modulate(const float* x, const float* w, const float* shift, const float* scale,
+                                int64_t mod_bstride, bf16_t* y, int M, int D, int ntok, int mode,
+                                hipStream_t s);
+// A[m=(b,tok)][k=c*4+p] = bf16(x[b][c][4*tok+p]) for the concatenated [x_t ; x_cond] channels.
+// x_t batch index = b % B_src; x_cond batch index = b (b < cond_zero_from) else zeros (CFG uncond half).
+hipError_t launch_patchify(const float* x_t, const float* x_cond, bf16_t* A, int B, int B_src,
+                           int cond_zero_from, int C_t, int C_c, int T_orig, int ntok, hipStream_t s);
+// sinusoidal embedding: e[b][i] = sin(t[b]*f_i), e[b][half+i] = cos(t[b]*f_i)  (jat_audiosr_v3.py:194-207)
+hipError_t launch_time_sinusoid(const float* t, float* e, int B, int D, hipStream_t s);
+// out[b][n] = act_out(sum_k in[b][k]*W[n][k] + bias[n]) in fp32; act_out: 0 none, 1 SiLU.
+// Optionally also writes bf16(silu(out)) to out_silu_bf16 (the adaLN GEMM's A operand).
+hipError_t launch_linear_f32(const float* in, const float* W, const float* bias, float* out,
+                             bf16_t* out_silu_bf16, int B, int N, int K, int act_out, hipStream_t s);
+hipError_t launch_silu_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
+hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
+// z += ((u + s(c-u)) - z)/(1-t+1e-5)*dt  (or z = x when t >= 0.999)  (infer_test_v3m2.py:161-179)
+hipError_t launch_cfg_euler(const float* xp, float* z, float cfg_scale, float t, float dt, int use_cfg,
+                            int64_t n_per_half, hipStream_t s);
+hipError_t launch_channel_affine(const float* in, const float* mean, const float* std, float* out, int B,
+                                 int C, int T, int inverse, hipStream_t s);
+hipError_t launch_crossfade_pair(const float* prev, int Tp, const float* cur, int Tc, int overlap,
+                                 float* out, int rows, hipStream_t s);

@@ -21,31 +21,38 @@ _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
 
 
-def _mix64(x: np.ndarray) -> np.ndarray:
-    """splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
-    x = x.copy()
-    x ^= x >> np.uint64(30)
-    x *= _M1
-    x ^= x >> np.uint64(27)
-    x *= _M2
-    x ^= x >> np.uint64(31)
-    return x
+def _hash24(idx: np.ndarray, seed: np.uint64) -> np.ndarray:
+    """24 well-mixed bits per element from (index, seed): one multiply-xorshift round on uint64 (wrap-around)."""
+    with np.errstate(over="ignore"):
+        h = idx * _GOLD
+        h += seed
+        h ^= h >> np.uint64(32)
+        h *= _M1
+        h ^= h >> np.uint64(29)
+        h *= _M2
+        h >>= np.uint64(40)
+    return h
 
 
 def name_seed(name: str, salt: int = 0) -> int:
     return (zlib.crc32(name.encode("utf-8")) | (salt << 32)) & 0xFFFFFFFFFFFFFFFF
 
 
+_CHUNK = 1 << 20
+
+
 def uniform(name: str, shape, salt: int = 0) -> np.ndarray:
-    """Uniform (-1, 1) fp32 array addressed by (name, salt, flat index)."""
+    """Uniform (-1, 1) fp32 array addressed by (name, salt, flat index); exact IEEE fp32 arithmetic."""
     n = int(np.prod(shape)) if len(shape) else 1
-    idx = np.arange(n, dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        seed = np.uint64(name_seed(name, salt))
-        h = _mix64(_mix64(idx * _GOLD + seed) ^ seed)
-    u24 = (h >> np.uint64(40)).astype(np.float64)  # 24 random bits
-    v = (u24 + 0.5) / float(1 << 24) * 2.0 - 1.0
-    return v.astype(np.float32).reshape(shape)
+    seed = np.uint64(name_seed(name, salt))
+    out = np.empty(n, dtype=np.float32)
+    for a in range(0, n, _CHUNK):          # chunked: stays in cache
+        b = min(a + _CHUNK, n)
+        u24 = _hash24(np.arange(a, b, dtype=np.uint64), seed).astype(np.float32)
+        u24 *= np.float32(2.0 ** -23)
+        u24 += np.float32(2.0 ** -24 - 1.0)
+        out[a:b] = u24
+    return out.reshape(shape)
 
 
 def gaussian(name: str, shape, salt: int = 0) -> np.ndarray:
@@ -123,8 +130,14 @@ def make_param(name: str, shape, salt: int = 0) -> np.ndarray:
     raise KeyError(name)
 
 
-def make_state_dict(cfg: dict, norm: str = "rms", salt: int = 0) -> "OrderedDict[str, np.ndarray]":
-    return OrderedDict((k, make_param(k, shp, salt)) for k, shp in model_param_shapes(cfg, norm).items())
+def make_state_dict(cfg: dict, norm: str = "rms", salt: int = 0, threads: int = 8) -> "OrderedDict[str, np.ndarray]":
+    shapes = model_param_shapes(cfg, norm)
+    if threads <= 1:
+        return OrderedDict((k, make_param(k, shp, salt)) for k, shp in shapes.items())
+    from concurrent.futures import ThreadPoolExecutor   # numpy ufuncs release the GIL
+    with ThreadPoolExecutor(threads) as ex:
+        vals = list(ex.map(lambda kv: make_param(kv[0], kv[1], salt), shapes.items()))
+    return OrderedDict(zip(shapes.keys(), vals))
 
 
 def rope_buffers(head_dim: int, max_seq_len: int = 4096, base: float = 10000.0):
@@ -140,6 +153,24 @@ def rope_buffers(head_dim: int, max_seq_len: int = 4096, base: float = 10000.0):
 def make_latents(B: int, C: int, T: int, salt: int = 0):
     """Synthetic normalised DAC latents: (x_t, x_cond) ~ N(0,1), shapes [B,C,T] fp32."""
     return gaussian("x_t", (B, C, T), salt), gaussian("x_cond", (B, C, T), salt)
+
+
+def forward_flops(cfg: dict, B: int, T: int) -> int:
+    """Algorithmic FLOPs of one DiT forward (1 MAC = 2 FLOP): the closed form of SURVEY.md §8d for any config,
+    FLOPs = B * [N * (per-token GEMM + attention terms) + per-sample (t_embedder + adaLN) terms], N = ceil(T/4).
+    Equal to torch.utils.flop_counter on the reference (tests/golden/misc.npz) — 127 627 689 984 per sample
+    at T=512 for v3mod2.  bench.py prices every roofline fraction with this figure."""
+    D = cfg["hidden_size"]; depth = cfg["depth"]; Hq = cfg["num_q_heads"]; Hkv = cfg["num_kv_heads"]
+    hd = D // Hq; kvD = Hkv * hd; P = cfg.get("patch_len", 4)
+    Cin = cfg.get("input_channels", 1024); Cc = cfg.get("cond_channels", 1024)
+    bott = cfg.get("bottleneck_dim", 512); mlp = int(D * cfg.get("mlp_ratio", 4.0))
+    N = -(-T // P)
+    per_tok = 2 * (P * (Cin + Cc) * bott + bott * D)
+    per_tok += depth * 2 * (D * (D + 2 * kvD) + D * D + 2 * D * mlp)
+    per_tok += depth * 2 * (2 * N * D)
+    per_tok += 2 * D * P * Cin
+    per_sample = 2 * (2 * D * D) + depth * 2 * (D * 6 * D)
+    return B * (N * per_tok + per_sample)
 
 
 # Named configurations (BASELINE.json `configs`; SURVEY.md §8a sizes A/B; micro = <10 MB exact-check case)

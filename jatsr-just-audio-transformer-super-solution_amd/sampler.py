@@ -1,0 +1,138 @@
+"""CFG flow-matching sampler and chunk driver — host-side mirror of reference infer_test_v3m2.py.
+
+`flow_matching_sample(model, lr_latent, num_steps, cfg_scale, device, verbose)` keeps the reference
+signature (infer_test_v3m2.py:107-185) and adds an optional `z0` (initial noise; the reference draws it
+with torch.randn at :133).  The whole loop — CFG double batch, 28-block forward, CFG combine, Euler update —
+runs as ONE hipGraph replay inside libjat_hip.so (`jat_sampler_run`); the schedule `linspace(0,1,steps+1)`
+and the `t < 0.999` branch (:173) are evaluated on the host, so no device scalar is ever read back.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class Sampler:
+    """A captured sampler for one (model, B, T, steps, cfg_scale) bucket: `jat_sampler_create` (include/jat_hip.h)."""
+
+    def __init__(self, model, B, T, num_steps=50, cfg_scale=1.0):
+        self.model = model
+        self.B, self.T, self.steps, self.cfg_scale = int(B), int(T), int(num_steps), float(cfg_scale)
+        h = model._get_handle()
+        self._handle = h
+        self._version = h.version
+        self.ptr = C.c_void_p()
+        L.check(L.lib().jat_sampler_create(h.ptr, self.B, self.T, self.steps, self.cfg_scale, C.byref(self.ptr)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                L.lib().jat_sampler_destroy(self.ptr)
+        except Exception:
+            pass
+
+    def run(self, lr_latent, z0, use_graph=True):
+        lr_latent = lr_latent.detach().to(torch.float32).contiguous()
+        z0 = z0.detach().to(torch.float32).contiguous()
+        if tuple(lr_latent.shape) != (self.B, self.model.input_channels, self.T) or z0.shape != lr_latent.shape:
+            raise ValueError(f"sampler bucket is [B={self.B}, C={self.model.input_channels}, T={self.T}], got "
+                             f"lr {tuple(lr_latent.shape)} z0 {tuple(z0.shape)}")
+        out = torch.empty_like(z0)
+        L.check(L.lib().jat_sampler_run(self.ptr, L.ptr(lr_latent), L.ptr(z0), L.ptr(out), 1 if use_graph else 0,
+                                        L.stream_ptr()))
+        return out
+
+
+def _cached_sampler(model, B, T, num_steps, cfg_scale):
+    cache = model.__dict__.setdefault("_jat_samplers", {})
+    key = (B, T, num_steps, float(cfg_scale))
+    s = cache.get(key)
+    h = model._get_handle()  # repacks if the weights changed
+    if s is None or s._version != h.version:
+        s = Sampler(model, B, T, num_steps, cfg_scale)
+        cache[key] = s
+    return s
+
+
+@torch.no_grad()
+def flow_matching_sample(model, lr_latent, num_steps=50, cfg_scale=1.0, device="cuda", verbose=True, z0=None,
+                         use_graph=True):
+    """Flow-matching Euler sampling with CFG (x-prediction), reference infer_test_v3m2.py:107-185.
+
+    lr_latent: [B, C, T] normalised LR latent.  Returns the generated [B, C, T] latent.
+    """
+    L.require_gpu()
+    lr_latent = lr_latent.to(device)
+    B, Cc, T = lr_latent.shape
+    if z0 is None:
+        z0 = torch.randn(B, Cc, T, device=lr_latent.device)      # :133
+    if verbose:
+        print(f"  Flow Matching sampling ({num_steps} steps, CFG scale={cfg_scale}) [hipGraph={bool(use_graph)}]")
+    s = _cached_sampler(model, B, T, num_steps, cfg_scale)
+    return s.run(lr_latent, z0.to(lr_latent.device), use_graph=use_graph)
+
+
+def crossfade_chunks(chunks, overlap_frames):
+    """Linear crossfade concatenation of [1, C, T_i] chunks — reference infer_test_v3m2.py:188-233."""
+    if len(chunks) == 0:
+        return None
+    if len(chunks) == 1:
+        return chunks[0]
+    L.require_gpu()
+    result = chunks[0].contiguous()
+    for cur in chunks[1:]:
+        cur = cur.contiguous()
+        ov = overlap_frames if (overlap_frames > 0 and result.shape[-1] >= overlap_frames) else 0   # :209, :229-231
+        rows = result.shape[0] * result.shape[1]
+        Tp, Tc = result.shape[-1], cur.shape[-1]
+        out = torch.empty(result.shape[0], result.shape[1], Tp + Tc - ov, dtype=torch.float32, device=result.device)
+        L.check(L.lib().jat_crossfade_pair(L.ptr(result), Tp, L.ptr(cur), Tc, ov, L.ptr(out), rows, L.stream_ptr()))
+        result = out
+    return result
+
+
+def chunk_plan(total_frames, chunk_frames=1378, overlap_frames=172):
+    """(start, end) of every chunk — reference infer_test_v3m2.py:340-361,370-372 (16 s chunks, 2 s overlap)."""
+    stride = chunk_frames - overlap_frames
+    num = (total_frames - overlap_frames + stride - 1) // stride
+    return [(i * stride, min(i * stride + chunk_frames, total_frames)) for i in range(num)]
+
+
+def channel_affine(x, mean, std, inverse=False):
+    """(x - mean_c)/std_c or x*std_c + mean_c per channel — reference infer_test_v3m2.py:381-382,394."""
+    L.require_gpu()
+    x = x.contiguous()
+    B, Cc, T = x.shape
+    out = torch.empty_like(x)
+    L.check(L.lib().jat_channel_affine(L.ptr(x), L.ptr(mean.contiguous().view(-1)), L.ptr(std.contiguous().view(-1)),
+                                       L.ptr(out), B, Cc, T, 1 if inverse else 0, L.stream_ptr()))
+    return out
+
+
+@torch.no_grad()
+def sample_long(model, lr_latent, hr_mean, hr_std, lr_mean, lr_std, num_steps=50, cfg_scale=1.0,
+                chunk_frames=1378, overlap_frames=172, noise=None):
+    """Chunked long-sequence inference == the chunk loop of infer_test_v3m2.py:340-404, with chunks of equal
+    length BATCHED into one sampler launch instead of the reference's serial B=1 loop.
+
+    lr_latent: [C, T_total] un-normalised latent.  noise: optional list of per-chunk z0 tensors [1,C,T_i].
+    Returns [1, C, T_total] de-normalised generated latent.
+    """
+    Cc, total = lr_latent.shape
+    plan = chunk_plan(total, chunk_frames, overlap_frames)
+    lr = lr_latent.unsqueeze(0)
+    by_len = {}
+    for i, (a, b) in enumerate(plan):
+        by_len.setdefault(b - a, []).append(i)
+    outs = [None] * len(plan)
+    for length, idxs in by_len.items():
+        batch = torch.cat([channel_affine(lr[:, :, plan[i][0]:plan[i][1]], lr_mean, lr_std) for i in idxs], 0)
+        z0 = None if noise is None else torch.cat([noise[i] for i in idxs], 0)
+        gen = flow_matching_sample(model, batch, num_steps, cfg_scale, device=batch.device, verbose=False, z0=z0)
+        gen = channel_affine(gen, hr_mean, hr_std, inverse=True)
+        for j, i in enumerate(idxs):
+            outs[i] = gen[j:j + 1]
+    return crossfade_chunks(outs, overlap_frames)

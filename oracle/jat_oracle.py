@@ -114,7 +114,7 @@ class OracleModel:
         self.P = cfg.get("patch_len", 4)
         self.Cin = cfg.get("input_channels", 1024)
         self.max_len = 2048                                                                # :361
-        self.sd = {k: np.asarray(v).astype(dtype) for k, v in sd.items() if ".rope." not in k}
+        self.sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items() if ".rope." not in k}
         self.stages = None  # filled by forward(record=True)
 
     # -- sub-blocks -------------------------------------------------------------------------------

@@ -1,0 +1,201 @@
+"""Per-kernel parity on the GPU, through the C ABI (include/jat_hip.h `jat_k_*`).
+
+Each HIP kernel is compared with a plain PyTorch evaluation of the same op on the SAME bf16-rounded
+operands (fp64 accumulate), so the only admissible differences are fp32 accumulation order and the final
+bf16 rounding: tolerances are stated per test.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import jatsr_amd._lib as L  # noqa: E402
+
+
+def dev():
+    L.require_gpu()
+    return torch.device("cuda:0")
+
+
+def bf16_bits(t):  # fp32 tensor -> (uint16-bits tensor as int16 view, rounded fp32 values)
+    b = t.to(torch.bfloat16)
+    return b, b.float()
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def gen(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev())
+
+
+def test_cast_bf16():
+    x = gen((3, 1001), 1)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().jat_k_cast_bf16(L.ptr(x), L.ptr(out), x.numel(), L.stream_ptr()))
+    assert torch.equal(out, x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("D,M,ntok,shared", [(1280, 257, 64, False), (512, 64, 32, True), (256, 9, 3, False)])
+def test_norm_modulate(mode, D, M, ntok, shared):
+    B = (M + ntok - 1) // ntok
+    x = gen((M, D), 2, 3.0) + 0.5
+    w = 1 + 0.2 * gen((D,), 3)
+    mod = gen((1 if shared else B, 2 * D), 4, 0.3)
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    shift, scale = mod[:, :D], mod[:, D:]
+    L.check(L.lib().jat_k_norm_modulate(L.ptr(x), L.ptr(w), C.c_void_p(mod.data_ptr()),
+                                        C.c_void_p(mod.data_ptr() + 4 * D), 0 if shared else 2 * D, L.ptr(y), M, D,
+                                        ntok, mode, L.stream_ptr()))
+    xd = x.double()
+    if mode == 0:
+        n = xd / torch.sqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * w.double()
+    elif mode == 1:
+        mu = xd.mean(-1, keepdim=True)
+        n = (xd - mu) / torch.sqrt(((xd - mu) ** 2).mean(-1, keepdim=True) + 1e-6)
+    else:
+        n = xd
+    bidx = torch.zeros(M, dtype=torch.long, device=x.device) if shared else torch.arange(M, device=x.device) // ntok
+    ref = n * (1 + scale.double()[bidx]) + shift.double()[bidx]
+    # fp32 statistics, one bf16 rounding of the result (2^-9 relative)
+    assert (y.double() - ref).abs().max() <= 2 ** -8 * ref.abs().max() + 1e-6
+    assert rel(y, ref) < 3e-3
+
+
+def test_norm_no_modulation():
+    D, M = 1280, 37
+    x = gen((M, D), 5)
+    w = 1 + 0.2 * gen((D,), 6)
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().jat_k_norm_modulate(L.ptr(x), L.ptr(w), None, None, 0, L.ptr(y), M, D, M, 0, L.stream_ptr()))
+    xd = x.double()
+    ref = xd / torch.sqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * w.double()
+    assert rel(y, ref) < 3e-3
+
+
+GEMM_SHAPES = [(128, 128, 64), (256, 512, 128), (1000, 1792, 1280), (56, 1536, 256), (1035, 1280, 5120),
+               (384, 256, 8192)]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm(variant, M, N, K, epi):
+    """C = A W^T (+bias) with epilogues fp32 / bf16 / bf16-GELU / gated residual; ragged M, asymmetric data."""
+    A, Af = bf16_bits(gen((M, K), 10 + epi))
+    W, Wf = bf16_bits(gen((N, K), 20 + epi, 1.0 / np.sqrt(K)))
+    bias = gen((N,), 30, 0.1)
+    ntok = 7 if M % 7 == 0 else (M if M < 64 else 23)
+    B = (M + ntok - 1) // ntok
+    gate = gen((B, N), 31, 0.5)
+    ref = Af.double() @ Wf.double().T + bias.double()
+    if epi == 0:
+        out = torch.full((M, N), float("nan"), device=A.device)
+    elif epi in (1, 2):
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device=A.device)
+    else:
+        out = gen((M, N), 32)
+        x0 = out.clone()
+    L.check(L.lib().jat_k_gemm(L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(out), M, N, K, epi, L.ptr(gate), N, ntok,
+                               variant, L.stream_ptr()))
+    torch.cuda.synchronize()
+    if epi == 0:
+        assert rel(out, ref) < 2e-6
+        assert (out.double() - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+    elif epi == 1:
+        assert rel(out, ref) < 3e-3
+        assert torch.equal(out, ref.float().to(torch.bfloat16)) or (out.float() - ref.float()).abs().max() <= \
+            2 ** -8 * float(ref.abs().max())
+    elif epi == 2:
+        g = torch.nn.functional.gelu(ref)  # erf form, fp64
+        assert (out.double() - g).abs().max() <= 2 ** -8 * float(g.abs().max()) + 1e-6
+        assert rel(out, g) < 3e-3
+    else:
+        bidx = torch.arange(M, device=A.device) // ntok
+        r = x0.double() + gate.double()[bidx] * ref
+        assert rel(out, r) < 2e-6
+
+
+def _attention_ref(q, k, v, B, N, Hq, Hkv):
+    g = Hq // Hkv
+    Q = q.double().view(B, N, Hq, 64).transpose(1, 2)
+    K = k.double().view(B, N, Hkv, 64).transpose(1, 2).repeat_interleave(g, dim=1)
+    V = v.double().view(B, N, Hkv, 64).transpose(1, 2).repeat_interleave(g, dim=1)
+    S = Q @ K.transpose(-1, -2) / 8.0
+    O = torch.softmax(S, -1) @ V
+    return O.transpose(1, 2).reshape(B * N, Hq * 64)
+
+
+@pytest.mark.parametrize("B,N,Hq,Hkv", [(2, 128, 20, 4), (1, 345, 20, 4), (3, 6, 4, 2), (1, 1024, 8, 4), (2, 70, 4, 4)])
+def test_attention(B, N, Hq, Hkv):
+    """softmax(q k^T/8) v with GQA head sharing; N ragged w.r.t. the 64-key block and the 128-query block."""
+    npad = (N + 63) // 64 * 64
+    q, qf = bf16_bits(gen((B * N, Hq * 64), 40, 1.5))
+    k, kf = bf16_bits(gen((B * N, Hkv * 64), 41, 1.5))
+    v, vf = bf16_bits(gen((B * N, Hkv * 64), 42))
+    vt = torch.zeros(B, Hkv, 64, npad, dtype=torch.bfloat16, device=q.device)
+    vt[:, :, :, :N] = v.view(B, N, Hkv, 64).permute(0, 2, 3, 1)
+    o = torch.zeros(B * N, Hq * 64, dtype=torch.bfloat16, device=q.device)
+    L.check(L.lib().jat_k_attention(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(o), B, N, Hq, Hkv, npad, L.stream_ptr()))
+    ref = _attention_ref(qf, kf, vf, B, N, Hq, Hkv)
+    # P is rounded to bf16 before PV and the output once more: ~2^-8 relative to the value scale
+    assert rel(o, ref) < 6e-3
+    assert (o.double() - ref).abs().max() < 2e-2 * float(ref.abs().max())
+
+
+def test_attention_spiky_rows():
+    """Online-softmax rescale across key blocks: one key in the LAST block dominates a query row."""
+    B, N, Hq, Hkv = 1, 256, 4, 2
+    npad = 256
+    qx = gen((B * N, Hq * 64), 50)
+    kx = gen((B * N, Hkv * 64), 51)
+    kx[200, :64] = qx[5, :64] * 4.0  # query 5 of head 0 / kv-head 0 spikes at key 200 (4th block)
+    kx[3, 64:] = qx[77, 128:192] * 4.0  # head 2 -> kv head 1 spikes in the first block
+    q, qf = bf16_bits(qx)
+    k, kf = bf16_bits(kx)
+    v, vf = bf16_bits(gen((B * N, Hkv * 64), 52))
+    vt = v.view(B, N, Hkv, 64).permute(0, 2, 3, 1).contiguous()
+    o = torch.zeros(B * N, Hq * 64, dtype=torch.bfloat16, device=q.device)
+    L.check(L.lib().jat_k_attention(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(o), B, N, Hq, Hkv, npad, L.stream_ptr()))
+    ref = _attention_ref(qf, kf, vf, B, N, Hq, Hkv)
+    assert rel(o, ref) < 6e-3
+    assert (o.double() - ref).abs().max() < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("use_cfg,t", [(True, 0.3), (False, 0.5), (True, 0.9995)])
+def test_cfg_euler_step(use_cfg, t):
+    """Bit-exact against the reference expression order (infer_test_v3m2.py:161-179) in fp32."""
+    B, Cc, T = 2, 8, 37
+    scale = 3.0 if use_cfg else 1.0
+    xp = gen((2 * B if use_cfg else B, Cc, T), 60)
+    z = gen((B, Cc, T), 61)
+    z0 = z.clone()
+    dt = 0.02
+    L.check(L.lib().jat_cfg_euler_step(L.ptr(xp), L.ptr(z), scale, t, dt, B, Cc, T, L.stream_ptr()))
+    x = xp[B:] + scale * (xp[:B] - xp[B:]) if use_cfg else xp
+    tt = torch.tensor(t, dtype=torch.float32)
+    if t < 0.999:
+        ref = z0 + (x - z0) / (1 - tt + 1e-5).to(x.device) * torch.tensor(dt, dtype=torch.float32, device=x.device)
+    else:
+        ref = x
+    assert torch.allclose(z, ref, rtol=0, atol=2e-6)
+    assert rel(z, ref) < 1e-6
+
+
+def test_channel_affine_roundtrip():
+    B, Cc, T = 2, 32, 50
+    x = gen((B, Cc, T), 70)
+    mean, std = gen((Cc,), 71), gen((Cc,), 72).abs() + 0.5
+    y = torch.empty_like(x)
+    L.check(L.lib().jat_channel_affine(L.ptr(x), L.ptr(mean), L.ptr(std), L.ptr(y), B, Cc, T, 0, L.stream_ptr()))
+    assert torch.allclose(y, (x - mean.view(1, -1, 1)) / std.view(1, -1, 1), atol=1e-6)
+    x2 = torch.empty_like(x)
+    L.check(L.lib().jat_channel_affine(L.ptr(y), L.ptr(mean), L.ptr(std), L.ptr(x2), B, Cc, T, 1, L.stream_ptr()))
+    assert torch.allclose(x2, x, atol=1e-5)

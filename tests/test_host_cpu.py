@@ -1,0 +1,140 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host validation
+mirrors the reference's error behaviour, state_dict layout matches the reference, and the product path
+fails loudly instead of falling back to a CPU implementation."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import jatsr_amd
+import jatsr_amd._lib as L
+import jatsr_amd.recipe as recipe
+from jatsr_amd.model import JaT_AudioSR_V2, JaT_AudioSR_V3, load_model
+from oracle import jat_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+no_gpu = not torch.cuda.is_available()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_lib():
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L.lib()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "jat_hip.h")).read()
+    declared = set(re.findall(r"\b(jat_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    nm = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (jat_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    assert built_lib.jat_version() >= 1
+
+
+def _create(**over):
+    base = dict(input_channels=1024, cond_channels=1024, patch_len=4, hidden_size=1280, depth=28, num_q_heads=20,
+                num_kv_heads=4, bottleneck_dim=512, mlp_hidden=5120, norm_mode=0)
+    base.update(over)
+    cfg = L.JatConfig(*[base[n] for n, _ in L.JatConfig._fields_])
+    h = C.c_void_p()
+    rc = L.lib().jat_model_create(C.byref(cfg), C.byref(h))
+    return rc, h
+
+
+def test_model_create_validation_and_workspace():
+    rc, h = _create()
+    assert rc == 0 and h
+    sizes = []
+    for B, T in [(1, 512), (28, 512), (56, 512), (56, 1378)]:
+        sz = C.c_size_t()
+        assert L.lib().jat_model_workspace_bytes(h, B, T, C.byref(sz)) == 0
+        sizes.append(sz.value)
+    assert sizes == sorted(sizes) and sizes[0] > 0
+    # forward before load_weights -> state error, never a silent fallback
+    rc2 = L.lib().jat_forward(h, None, None, None, None, 1, 8, None, 0, None)
+    assert rc2 == L.JAT_E_STATE
+    L.lib().jat_model_destroy(h)
+    for bad in (dict(num_q_heads=3), dict(num_kv_heads=3), dict(patch_len=2), dict(hidden_size=1000, num_q_heads=10),
+                dict(norm_mode=7), dict(depth=0)):
+        rc, _ = _create(**bad)
+        assert rc == L.JAT_E_INVALID, bad
+        assert L.lib().jat_last_error()
+
+
+@pytest.mark.parametrize("cfg_name", ["micro", "tiny"])
+@pytest.mark.parametrize("norm", ["rms", "ln"])
+def test_state_dict_layout_matches_reference(cfg_name, norm):
+    cfg = recipe.CONFIGS[cfg_name]
+    m = (JaT_AudioSR_V3 if norm == "rms" else JaT_AudioSR_V2)(**cfg, dropout=0.1, drop_path_rate=0.05)
+    sd = m.state_dict()
+    want = recipe.model_param_shapes(cfg, norm)
+    params = {k: tuple(v.shape) for k, v in sd.items() if ".rope." not in k}
+    assert params == dict(want)
+    # persistent RoPE buffers are part of the reference checkpoint format (jat_audiosr_v3.py:78,84-85)
+    inv, cos, sin = recipe.rope_buffers(64)
+    assert torch.allclose(sd["blocks.0.attn.rope.inv_freq"], torch.from_numpy(inv), rtol=1e-6)
+    assert sd["blocks.0.attn.rope.cos_cached"].shape == (4096, 64)
+    # 1-ulp differences in powf() for inv_freq grow to ~2e-4 rad at position 4095
+    assert torch.allclose(sd["blocks.1.attn.rope.sin_cached"], torch.from_numpy(sin), atol=1e-3)
+    # zero-init of adaLN + final linear (jat_audiosr_v3.py:395-404)
+    assert float(sd["blocks.0.adaLN_modulation.1.weight"].abs().max()) == 0.0
+    assert float(sd["final_layer.1.weight"].abs().max()) == 0.0
+
+
+def test_load_model_strips_prefixes_and_is_non_strict():
+    cfg = recipe.CONFIGS["micro"]
+    sd = {("_orig_mod.module." + k): torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg).items()}
+    sd.pop("_orig_mod.module.blocks.0.norm1.weight")     # strict=False: missing keys tolerated (:74)
+    ck = {"model_state_dict": sd, "config": dict(cfg, dropout=0.1, drop_path_rate=0.05), "epoch": 3, "global_step": 99}
+    m = load_model(ck, device="cpu")
+    assert isinstance(m, JaT_AudioSR_V3) and not m.training
+    assert m.load_info["epoch"] == 3 and "blocks.0.norm1.weight" in m.load_info["missing"]
+    assert torch.equal(m.blocks[1].attn.q_proj.weight, sd["_orig_mod.module.blocks.1.attn.q_proj.weight"])
+
+
+@pytest.mark.skipif(not no_gpu, reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    m = JaT_AudioSR_V3(**recipe.CONFIGS["micro"])
+    x = torch.zeros(1, 32, 8)
+    with pytest.raises(L.JatError):
+        m(x, torch.zeros(1), x)
+    with pytest.raises(L.JatError):
+        jatsr_amd.flow_matching_sample(m, x, num_steps=2, verbose=False)
+    with pytest.raises(L.JatError):
+        m.blocks[0](torch.zeros(1, 2, 256), torch.zeros(1, 256))
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never import or call the oracle (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, "jatsr-just-audio-transformer-super-solution_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dp, f), encoding="utf-8").read().replace(
+                    "CPU oracle", "").replace("the oracle", ""), f
+
+
+def test_recipe_is_deterministic_and_flops_closed_form():
+    u = recipe.uniform("a", (4,))
+    assert np.allclose(u, [-0.16541618, 0.8985061, 0.58957404, 0.12038141])
+    assert recipe.forward_flops(recipe.CONFIGS["v3mod2"], 1, 512) == 127627689984
+    for c, B, T in (("tiny", 2, 128), ("micro", 3, 22), ("v3mod2", 28, 1378)):
+        assert recipe.forward_flops(recipe.CONFIGS[c], B, T) == O.forward_flops(recipe.CONFIGS[c], B, T)
+
+
+def test_chunk_plan_and_shard_range():
+    from jatsr_amd.dist import shard_range
+    from jatsr_amd.sampler import chunk_plan
+    assert chunk_plan(4096) == O.chunk_plan(4096)
+    assert chunk_plan(500, 200, 40) == O.chunk_plan(500, 200, 40)
+    sizes = [shard_range(28, 8, r) for r in range(8)]
+    assert [b - a for a, b in sizes] == [4, 4, 4, 4, 3, 3, 3, 3]
+    assert sizes[0][0] == 0 and sizes[-1][1] == 28 and all(sizes[i][1] == sizes[i + 1][0] for i in range(7))
+    assert shard_range(2, 4, 3) == (2, 2)
