@@ -235,6 +235,23 @@ hipError_t launch_silu_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t
   return hipGetLastError();
 }
 
+__global__ void cast_bf16_rope_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  const int h = r >> 6, q = r & 63;
+  const int src = (h << 6) + (q >> 1) + ((q & 1) << 5);
+  const float4 v = *(const float4*)(in + (int64_t)src * cols + c);
+  *(uint2*)(out + i) = pack4_e(v.x, v.y, v.z, v.w);
+}
+hipError_t launch_cast_bf16_rope_rows(const float* in, bf16_t* out, int rows, int cols, hipStream_t s) {
+  if (rows % 64 != 0 || cols % 4 != 0) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(cast_bf16_rope_rows_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, in, out, rows,
+                     cols);
+  return hipGetLastError();
+}
+
 // ---- CFG combine + Euler step (infer_test_v3m2.py:161-179) ----------------------------------------------
 // x = u + s (c - u);  z += (x - z) / (1 - t + 1e-5) * dt   (t < 0.999)   |   z = x   (otherwise)
 // The branch depends only on the host-side schedule, so it is a kernel argument, not a device read.

@@ -1,16 +1,27 @@
 // bf16 MFMA GEMM for gfx950 with fused epilogues:  C[M,N] = A[M,K] * W[N,K]^T.
 //
 // Both operands are K-contiguous (activations [tokens, features], nn.Linear weights [out, in]), so A and
-// W fragments are fetched the same way.  Structure (cdna_hip_programming.md §5 / T2 / T3 "minimum 2-phase"):
+// W fragments are fetched the same way.  Common to every variant (cdna_hip_programming.md §5, T1, T2):
 //   - BK = 64; LDS image per operand = [rows][128 B], 16-B chunks XOR-swizzled by (row & 7) so that the
 //     ds_read_b128 fragment reads are bank-conflict free;
 //   - global -> LDS by global_load_lds_dwordx4 (1 KiB per wave-instruction, LDS image lane-linear, the
 //     swizzle applied on the per-lane SOURCE address and again on the read: rule 21);
-//   - 2 LDS stages, one barrier per K-tile, the next tile's DMA in flight under the current tile's MFMAs;
 //   - v_mfma_f32_16x16x32_bf16 with the operands SWAPPED (W fragment as A, activation fragment as B):
 //     the accumulator tile is then C^T, i.e. each lane owns 4 CONSECUTIVE output features of ONE row,
-//     which makes every epilogue store 8-16 B wide and lets RoPE pair (d, d+32) in registers;
-//   - XCD-aware block remap (bijective) + grouped-M tile order for L2 reuse.
+//     which makes every epilogue store 8-16 B wide and keeps RoPE pairs in one lane (see EPI_QKV_ROPE);
+//   - XCD-aware block remap (bijective) + grouped-M tile order for L2 reuse;
+//   - tile shape is a template parameter (WM x WN waves, TM x TN 16x16 MFMA tiles per wave): the model
+//     picks, per GEMM, the shape whose tile count quantises best onto 256 CUs.
+// Two main-loop structures:
+//   PIPE 0  one barrier per K-tile, next tile's DMA in flight under the current tile's MFMAs; fragment
+//           reads scheduled by the compiler ("minimum 2-phase" loop of T3).
+//   PIPE 1/2 one barrier per K-tile placed MID-tile (1: MFMA clusters fenced by s_setprio, 2: ds_read/MFMA
+//           interleave requested with sched_group_barrier), fragments double-buffered in registers and always read
+//           one k-step ahead of the MFMAs that use them (also across the tile boundary), so no LDS latency
+//           and no DMA wait is exposed at the top of a tile:
+//             phase A: MFMA(F0: tile t, k-step 0)  ||  ds_read F1 <- tile t, k-step 1
+//             s_waitcnt (F1 in regs, my DMA pieces of tile t+1 landed) ; barrier ; DMA tile t+2 -> stage of t
+//             phase B: MFMA(F1)                    ||  ds_read F0 <- tile t+1, k-step 0
 // M may be ragged (rows clamped on load, masked on store); N % BN == 0 and K % 64 == 0 are required.
 #include "jat_kernels.h"
 
@@ -43,14 +54,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
-template <int WM, int WN, int TM, int TN, int EPI>
-__global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs p) {
+// 4-wave blocks with <= 20 accumulator tiles per wave are meant to run two per CU (2 waves per SIMD): cap the
+// register allocation accordingly (2nd launch-bounds argument = waves per SIMD).
+template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
+    gemm_bf16_kernel(const GemmArgs p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 64;
   constexpr int NW = WM * WN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // 1-KiB DMA pieces per wave per K-tile
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
-  static_assert(EPI != EPI_QKV_ROPE || TN == 4, "RoPE epilogue needs a 64-wide wave tile (one head)");
+  constexpr int PA = BM / 8, PB = BN / 8;                       // 1-KiB DMA pieces per operand per K-tile
+  constexpr int AI = (PA + NW - 1) / NW, BI = (PB + NW - 1) / NW;  // pieces per wave (last may be idle)
+  static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must be a multiple of 8");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,13 +94,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
   const bf16_t* b_src[BI];
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
-    const int r = (wave * AI + j) * 8 + srow;
+    const int r = min(wave + j * NW, PA - 1) * 8 + srow;
     const int gm = min(m0 + r, p.M - 1);
     a_src[j] = p.A + (int64_t)gm * p.lda + schunk * 8;
   }
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
-    const int r = (wave * BI + j) * 8 + srow;
+    const int r = min(wave + j * NW, PB - 1) * 8 + srow;
     b_src[j] = p.W + (int64_t)(n0 + r) * p.ldw + schunk * 8;
   }
   auto stage = [&](int st, int kt) {
@@ -95,12 +109,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
     const int koff = kt * BK;
 #pragma unroll
     for (int j = 0; j < AI; ++j)
-      __builtin_amdgcn_global_load_lds((const void*)(a_src[j] + koff), (lds_ptr_t)(sA + (wave * AI + j) * 1024),
-                                       16, 0, 0);
+      if (PIPE == 3 || PA % NW == 0 || wave + j * NW < PA)
+        __builtin_amdgcn_global_load_lds((const void*)(a_src[j] + koff),
+                                         (lds_ptr_t)(sA + min(wave + j * NW, PA - 1) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < BI; ++j)
-      __builtin_amdgcn_global_load_lds((const void*)(b_src[j] + koff), (lds_ptr_t)(sB + (wave * BI + j) * 1024),
-                                       16, 0, 0);
+      if (PIPE == 3 || PB % NW == 0 || wave + j * NW < PB)
+        __builtin_amdgcn_global_load_lds((const void*)(b_src[j] + koff),
+                                         (lds_ptr_t)(sB + min(wave + j * NW, PB - 1) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[TM][TN];
@@ -112,34 +128,213 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
   const int frow = lane & 15, fg = lane >> 4;
   const int a_row_off = (wm * TM * 16 + frow) * 128;
   const int b_row_off = (wn * TN * 16 + frow) * 128;
+  const int coff0 = ((0 + fg) ^ (frow & 7)) * 16, coff1 = ((4 + fg) ^ (frow & 7)) * 16;
 
-  const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sA = smem + cur * STAGE;
+  auto read_frags = [&](bf16x8(&af)[TM], bf16x8(&wf)[TN], int st, int coff) {
+    const char* sA = smem + st * STAGE;
     const char* sB = sA + A_BYTES;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int coff = ((s * 4 + fg) ^ (frow & 7)) * 16;
+    for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(sA + a_row_off + i * 2048 + coff);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(sB + b_row_off + j * 2048 + coff);
+  };
+  auto mma = [&](const bf16x8(&af)[TM], const bf16x8(&wf)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+
+  const int nk = p.K / BK;
+  if constexpr (PIPE == 0) {
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
       bf16x8 af[TM], wf[TN];
+      read_frags(af, wf, cur, coff0);
+      mma(af, wf);
+      read_frags(af, wf, cur, coff1);
+      mma(af, wf);
+    }
+  } else if constexpr (PIPE == 3) {
+    // 3-stage LDS ring, TWO K-tiles of DMA in flight under the MFMAs: counted s_waitcnt vmcnt (never 0 in the
+    // steady state) + raw s_barrier (a __syncthreads() would drain the DMA queue: "Pipelining across barriers").
+    constexpr int PW = AI + BI;  // DMA pieces per wave per K-tile (uniform: stage() pads with duplicates)
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, kt + 2);
+      bf16x8 af[TM], wf[TN];
+      read_frags(af, wf, cur, coff0);
+      mma(af, wf);
+      read_frags(af, wf, cur, coff1);
+      mma(af, wf);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+  } else {
+    // interleave hint: one fragment read, then MPR MFMAs, ... (sched_group_barrier masks: MFMA 0x8, DS read 0x100)
+    constexpr int NREAD = TM + TN, NMMA = TM * TN, MPR = NMMA / NREAD;
+    auto interleave = [&]() {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(sA + a_row_off + i * 2048 + coff);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(sB + b_row_off + j * 2048 + coff);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      for (int r = 0; r < NREAD; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMMA - MPR * NREAD, 0);
+    };
+    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nk > 1) stage(1, 1);
+    read_frags(a0, w0, 0, coff0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      // phase A: MFMAs of k-step 0 while the fragments of k-step 1 stream in
+      read_frags(a1, w1, cur, coff1);
+      if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(1);
+      mma(a0, w0);
+      if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(0);
+      if constexpr (PIPE == 2) interleave();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile kt+1 have landed
+      __syncthreads();                                   // everyone holds F1 in registers: stage `cur` is free
+      if (kt + 2 < nk) stage(cur, kt + 2);
+      // phase B: MFMAs of k-step 1 while the first fragments of tile kt+1 stream in (harmless when kt+1 == nk)
+      read_frags(a0, w0, cur ^ 1, coff0);
+      if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(1);
+      mma(a1, w1);
+      if constexpr (PIPE == 1) __builtin_amdgcn_s_setprio(0);
+      if constexpr (PIPE == 2) interleave();
     }
   }
 
-  // ---- epilogue: lane owns C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg -----------
   const int nw0 = n0 + wn * TN * 16;  // wave-uniform first column
+
+  // ---- coalesced epilogue (CE): accumulators -> wave-private LDS slab (32 rows at a time) -> each lane
+  // reads back 16 B that are CONTIGUOUS along n, so global loads/stores cover whole rows of the wave tile
+  // (full 128-B lines) instead of 8-16 B per lane at a row stride.
+  if constexpr (CE && EPI <= EPI_RESID) {
+    static_assert(TM % 2 == 0, "coalesced epilogue walks the wave tile 32 rows at a time");
+    constexpr bool OUT32 = (EPI == EPI_F32 || EPI == EPI_RESID);
+    constexpr int EB = OUT32 ? 4 : 2;        // bytes per output element
+    constexpr int EPC = 16 / EB;             // elements per 16-B chunk
+    constexpr int RS = TN * 16 * EB + 16;    // padded LDS row stride (bytes)
+    constexpr int CPR = TN * 16 / EPC;       // chunks per row
+    constexpr int NCH = 32 * CPR / 64;       // chunks per lane per 32-row group
+    static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
+    __syncthreads();                          // every wave is done reading the staging buffers
+    if (p.dbg & 1) return;
+    char* wbuf = smem + wave * (32 * RS);
+    const int mw0 = m0 + wm * TM * 16;
+    float4 bb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ig = 0; ig < TM / 2; ++ig) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x4 v = acc[2 * ig + ii][j];
+          v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w;
+          char* dst = wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * EB;
+          if constexpr (OUT32) {
+            *(float4*)dst = float4{v[0], v[1], v[2], v[3]};
+          } else if constexpr (EPI == EPI_BF16_GELU) {
+            *(uint2*)dst = pack4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+          } else {
+            *(uint2*)dst = pack4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < NCH; ++t) {
+        const int c = lane + 64 * t, row = c / CPR, cc = c - row * CPR;
+        const int m = mw0 + ig * 32 + row, n = nw0 + cc * EPC;
+        const uint4 raw = *(const uint4*)(wbuf + row * RS + cc * 16);
+        if (m < p.M) {
+          if constexpr (EPI == EPI_RESID) {
+            const int b = m / p.ntok;
+            const float4 g = *(const float4*)(p.gate + (int64_t)b * p.gate_bstride + n);
+            float4* xp = (float4*)((float*)p.out + (int64_t)m * p.ldo + n);
+            float4 x = *xp;
+            x.x += g.x * __uint_as_float(raw.x); x.y += g.y * __uint_as_float(raw.y);
+            x.z += g.z * __uint_as_float(raw.z); x.w += g.w * __uint_as_float(raw.w);
+            *xp = x;
+          } else if constexpr (EPI == EPI_F32) {
+            *(uint4*)((float*)p.out + (int64_t)m * p.ldo + n) = raw;
+          } else {
+            *(uint4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = raw;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+
+  // ---- coalesced QKV epilogue: RoPE in registers, q/k through the LDS slab (16-B row-contiguous stores into
+  // the q / k buffers), v tiles stored transposed directly (runs of 16 tokens per feature).
+  if constexpr (CE && EPI == EPI_QKV_ROPE) {
+    static_assert(TM % 2 == 0, "coalesced epilogue walks the wave tile 32 rows at a time");
+    constexpr int RS = TN * 32 + 16, CPR = TN * 2, NCH = 32 * CPR / 64;
+    static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
+    __syncthreads();
+    if (p.dbg & 1) return;
+    char* wbuf = smem + wave * (32 * RS);
+    const int mw0 = m0 + wm * TM * 16;
+    const int nqk = p.D + p.kvD;
+#pragma unroll
+    for (int ig = 0; ig < TM / 2; ++ig) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int m = min(mw0 + (2 * ig + ii) * 16 + frow, p.M - 1);
+        const int b = m / p.ntok, pos = m - b * p.ntok;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nt = nw0 + j * 16;
+          const f32x4 v = acc[2 * ig + ii][j];
+          if (nt < nqk) {
+            const int d0 = ((nt & 63) >> 1) + fg * 2;
+            const float2 c = *(const float2*)(p.rope_cos + (int64_t)pos * 32 + d0);
+            const float2 s = *(const float2*)(p.rope_sin + (int64_t)pos * 32 + d0);
+            *(uint2*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 2) =
+                pack4(v[0] * c.x - v[1] * s.x, v[1] * c.x + v[0] * s.x, v[2] * c.y - v[3] * s.y,
+                      v[3] * c.y + v[2] * s.y);
+          } else if (mw0 + (2 * ig + ii) * 16 + frow < p.M) {
+            const int nv = nt + fg * 4 - nqk;
+            bf16_t* dst = p.vt_out + ((int64_t)(b * (p.kvD >> 6) + (nv >> 6)) * 64 + (nv & 63)) * p.npad + pos;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.npad] = f2bf(v[r]);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < NCH; ++t) {
+        const int c = lane + 64 * t, row = c / CPR, cc = c - row * CPR;
+        const int m = mw0 + ig * 32 + row, n = nw0 + cc * 8;
+        const uint4 raw = *(const uint4*)(wbuf + row * RS + cc * 16);
+        if (m < p.M && n < nqk) {
+          bf16_t* dst = (n < p.D) ? ((bf16_t*)p.out + (int64_t)m * p.D + n) : (p.k_out + (int64_t)m * p.kvD + (n - p.D));
+          *(uint4*)dst = raw;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+
+  // ---- direct epilogue: lane owns C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg -----------
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * TM * 16 + i * 16 + frow;
@@ -149,38 +344,32 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
       b = m / p.ntok;
       pos = m - b * p.ntok;
     }
-    if constexpr (EPI == EPI_QKV_ROPE) {
-      // wave tile = one 64-wide head; RoPE pairs (d, d+32) = accumulator tiles (j, j+2), same lane/reg
-      const int dl = fg * 4;
-      if (nw0 < p.D + p.kvD) {  // q or k head: rotate (jat_audiosr_v3.py:87-108)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float4 c = *(const float4*)(p.rope_cos + (int64_t)pos * 32 + j * 16 + dl);
-          const float4 s = *(const float4*)(p.rope_sin + (int64_t)pos * 32 + j * 16 + dl);
-          const f32x4 x1 = acc[i][j], x2 = acc[i][j + 2];
-          acc[i][j] = f32x4{x1[0] * c.x - x2[0] * s.x, x1[1] * c.y - x2[1] * s.y, x1[2] * c.z - x2[2] * s.z,
-                            x1[3] * c.w - x2[3] * s.w};
-          acc[i][j + 2] = f32x4{x2[0] * c.x + x1[0] * s.x, x2[1] * c.y + x1[1] * s.y,
-                                x2[2] * c.z + x1[2] * s.z, x2[3] * c.w + x1[3] * s.w};
+    for (int j = 0; j < TN; ++j) {
+      const int nt = nw0 + j * 16;          // wave-uniform first column of this 16-wide MFMA tile
+      const int n = nt + fg * 4;
+      f32x4 v = acc[i][j];
+      if ((p.dbg & 1) && v[0] != 12345.678f) continue;
+      if constexpr (EPI == EPI_QKV_ROPE) {
+        // Wq / Wk rows are packed pair-interleaved per head (position 2d <- feature d, 2d+1 <- feature d+32),
+        // so the RoPE pair (d, d+32) (jat_audiosr_v3.py:87-108) sits in adjacent registers of one lane.
+        // q.k is invariant under this shared permutation; V is not permuted.
+        if (nt < p.D + p.kvD) {
+          const int d0 = ((nt & 63) >> 1) + fg * 2;
+          const float2 c = *(const float2*)(p.rope_cos + (int64_t)pos * 32 + d0);
+          const float2 s = *(const float2*)(p.rope_sin + (int64_t)pos * 32 + d0);
+          const float o0 = v[0] * c.x - v[1] * s.x, o1 = v[1] * c.x + v[0] * s.x;
+          const float o2 = v[2] * c.y - v[3] * s.y, o3 = v[3] * c.y + v[2] * s.y;
+          bf16_t* dst = (nt < p.D) ? ((bf16_t*)p.out + (int64_t)m * p.D + n)
+                                   : (p.k_out + (int64_t)m * p.kvD + (n - p.D));
+          *(uint2*)dst = pack4(o0, o1, o2, o3);
+        } else {  // v head: store transposed vt[b][hv][d][pos]
+          const int nv = n - p.D - p.kvD;
+          bf16_t* dst = p.vt_out + ((int64_t)(b * (p.kvD >> 6) + (nv >> 6)) * 64 + (nv & 63)) * p.npad + pos;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.npad] = f2bf(v[r]);
         }
-        bf16_t* dst = (nw0 < p.D) ? ((bf16_t*)p.out + (int64_t)m * p.D + nw0)
-                                  : (p.k_out + (int64_t)m * p.kvD + (nw0 - p.D));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          *(uint2*)(dst + j * 16 + dl) = pack4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      } else {  // v head: store transposed vt[b][hv][d][pos]
-        const int hv = (nw0 - p.D - p.kvD) >> 6;
-        bf16_t* dst = p.vt_out + ((int64_t)(b * (p.kvD >> 6) + hv) * 64) * p.npad + pos;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dst[(int64_t)(j * 16 + dl + r) * p.npad] = f2bf(acc[i][j][r]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = nw0 + j * 16 + fg * 4;
-        f32x4 v = acc[i][j];
+      } else {
         if (p.bias) {
           const float4 bb = *(const float4*)(p.bias + n);
           v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -215,12 +404,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_kernel(const GemmArgs 
 }
 
 // -----------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = (PIPE == 3 ? 3 : 2) * (BM + BN) * 128;
+  static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<WM, WN, TM, TN, EPI>;
+  auto kern = gemm_bf16_kernel<WM, WN, TM, TN, PIPE, CE, EPI>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
@@ -232,28 +422,60 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int PIPE, int CE = 0>
 static hipError_t launch_epi(const GemmArgs& a, int epi, hipStream_t s) {
   switch (epi) {
-    case EPI_F32: return launch_one<WM, WN, TM, TN, EPI_F32>(a, s);
-    case EPI_BF16: return launch_one<WM, WN, TM, TN, EPI_BF16>(a, s);
-    case EPI_BF16_GELU: return launch_one<WM, WN, TM, TN, EPI_BF16_GELU>(a, s);
-    case EPI_RESID: return launch_one<WM, WN, TM, TN, EPI_RESID>(a, s);
-    case EPI_QKV_ROPE: return launch_one<WM, WN, TM, TN, EPI_QKV_ROPE>(a, s);
-    case EPI_UNPATCH: return launch_one<WM, WN, TM, TN, EPI_UNPATCH>(a, s);
+    case EPI_F32: return launch_one<WM, WN, TM, TN, PIPE, CE, EPI_F32>(a, s);
+    case EPI_BF16: return launch_one<WM, WN, TM, TN, PIPE, CE, EPI_BF16>(a, s);
+    case EPI_BF16_GELU: return launch_one<WM, WN, TM, TN, PIPE, CE, EPI_BF16_GELU>(a, s);
+    case EPI_RESID: return launch_one<WM, WN, TM, TN, PIPE, CE, EPI_RESID>(a, s);
+    case EPI_QKV_ROPE: return launch_one<WM, WN, TM, TN, PIPE, CE, EPI_QKV_ROPE>(a, s);
+    case EPI_UNPATCH: return launch_one<WM, WN, TM, TN, PIPE, CE, EPI_UNPATCH>(a, s);
   }
   return hipErrorInvalidValue;
 }
 
-int gemm_num_variants() { return 3; }
+// variant table: {BM, BN} per id (for the host-side chooser) and the dispatch below must stay in sync
+static const int kVariantTile[][2] = {
+    {128, 128}, {256, 128}, {256, 256},              // 0-2: PIPE 0
+    {128, 128}, {128, 160}, {256, 160}, {256, 128},  // 3-6: PIPE 1
+    {256, 256}, {224, 160}, {224, 224}, {128, 64},   // 7-10: PIPE 1
+    {128, 128}, {128, 160}, {256, 160}, {224, 160},  // 11-14: PIPE 2
+    {256, 128}, {256, 160}, {256, 128},              // 15-17: PIPE 3 (3-stage ring; 17 = 2x4 waves of 128x32)
+    {128, 160}, {256, 160}, {128, 128}, {256, 256},  // 18-21: PIPE 2 + coalesced epilogue
+};
+int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
+void gemm_variant_tile(int variant, int* bm, int* bn) {
+  *bm = kVariantTile[variant][0];
+  *bn = kVariantTile[variant][1];
+}
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
-  // fall back to the 128-wide tile whenever N is not a multiple of 256
-  if (variant == 2 && a.N % 256 != 0) variant = 0;
+  if (variant < 0 || variant >= gemm_num_variants()) return hipErrorInvalidValue;
+  if (a.N % kVariantTile[variant][1] != 0) variant = (a.N % 128 == 0) ? 3 : 10;  // always-valid fallbacks
   switch (variant) {
-    case 0: return launch_epi<2, 2, 4, 4>(a, epi, s);  // 128 x 128, 4 waves
-    case 1: return launch_epi<4, 2, 4, 4>(a, epi, s);  // 256 x 128, 8 waves
-    case 2: return launch_epi<2, 4, 8, 4>(a, epi, s);  // 256 x 256, 8 waves
+    case 0: return launch_epi<2, 2, 4, 4, 0>(a, epi, s);
+    case 1: return launch_epi<4, 2, 4, 4, 0>(a, epi, s);
+    case 2: return launch_epi<2, 4, 8, 4, 0>(a, epi, s);
+    case 3: return launch_epi<2, 2, 4, 4, 1>(a, epi, s);
+    case 4: return launch_epi<2, 2, 4, 5, 1>(a, epi, s);
+    case 5: return launch_epi<4, 2, 4, 5, 1>(a, epi, s);
+    case 6: return launch_epi<4, 2, 4, 4, 1>(a, epi, s);
+    case 7: return launch_epi<2, 4, 8, 4, 1>(a, epi, s);
+    case 8: return launch_epi<2, 2, 7, 5, 1>(a, epi, s);
+    case 9: return launch_epi<2, 2, 7, 7, 1>(a, epi, s);
+    case 10: return launch_epi<2, 2, 4, 2, 1>(a, epi, s);
+    case 11: return launch_epi<2, 2, 4, 4, 2>(a, epi, s);
+    case 12: return launch_epi<2, 2, 4, 5, 2>(a, epi, s);
+    case 13: return launch_epi<4, 2, 4, 5, 2>(a, epi, s);
+    case 14: return launch_epi<2, 2, 7, 5, 2>(a, epi, s);
+    case 15: return launch_epi<4, 2, 4, 4, 3>(a, epi, s);
+    case 16: return launch_epi<4, 2, 4, 5, 3>(a, epi, s);
+    case 17: return launch_epi<2, 4, 8, 2, 3>(a, epi, s);
+    case 18: return launch_epi<2, 2, 4, 5, 2, 1>(a, epi, s);
+    case 19: return launch_epi<4, 2, 4, 5, 2, 1>(a, epi, s);
+    case 20: return launch_epi<2, 2, 4, 4, 2, 1>(a, epi, s);
+    case 21: return launch_epi<2, 4, 8, 4, 2, 1>(a, epi, s);
   }
   return hipErrorInvalidValue;
 }

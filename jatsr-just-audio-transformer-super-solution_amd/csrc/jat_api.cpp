@@ -54,8 +54,10 @@ struct jat_model {
   bf16_t *pe_w1, *pe_w2, *wada, *wfinal;
   float *pe_b1, *pe_b2, *te_w1, *te_b1, *te_w2, *te_b2, *bada, *final_norm, *bfinal, *rope_cos, *rope_sin;
   std::vector<LayerW> layers;
-  int gemm_variant = 0;
+  // GEMM tile/pipeline variant per call site: qkv, out_proj, fc1, fc2, everything else (gemm.hip table)
+  int variants[5] = {-1, -1, -1, -1, -1};  // -1: choose by shape (pick_variant)
 };
+enum { G_QKV = 0, G_OUT = 1, G_FC1 = 2, G_FC2 = 3, G_OTHER = 4 };
 
 // workspace carve-up for a forward over `B` batch rows of `ntok` tokens
 struct Workspace {
@@ -124,7 +126,13 @@ extern "C" int jat_model_create(const jat_config* c, jat_model** out) {
   m->kvD = m->Hkv * HEAD_DIM; m->mlp = c->mlp_hidden; m->bott = c->bottleneck_dim;
   m->Cin = c->input_channels; m->Cc = c->cond_channels; m->P = 4;
   m->Kp = m->P * (m->Cin + m->Cc); m->Fout = m->P * m->Cin;
-  if (const char* v = getenv("JAT_GEMM_VARIANT")) m->gemm_variant = atoi(v);
+  if (const char* v = getenv("JAT_GEMM_VARIANT"))
+    for (int i = 0; i < 5; ++i) m->variants[i] = atoi(v);
+  if (const char* v = getenv("JAT_GEMM_VARIANTS")) {  // "qkv,out,fc1,fc2,other"
+    int x[5];
+    if (sscanf(v, "%d,%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3], &x[4]) == 5)
+      for (int i = 0; i < 5; ++i) m->variants[i] = x[i];
+  }
   *out = m;
   return JAT_OK;
 }
@@ -199,6 +207,11 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
     if (!src) return;
     if (launch_cast_bf16(src, dst, numel, s) != hipSuccess) rc = fail(JAT_E_HIP, "cast kernel launch failed");
   };
+  auto to_bf16_rope = [&](const std::string& name, bf16_t* dst, int rows, int cols) {
+    const float* src = find(name, (int64_t)rows * cols);
+    if (!src) return;
+    if (launch_cast_bf16_rope_rows(src, dst, rows, cols, s) != hipSuccess) rc = fail(JAT_E_HIP, "cast kernel launch failed");
+  };
   auto to_f32 = [&](const std::string& name, float* dst, int64_t numel) {
     const float* src = find(name, numel);
     if (!src) return;
@@ -223,8 +236,9 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
     LayerW& L = m->layers[l];
     if (rms) { to_f32(p + "norm1.weight", L.norm1, D); to_f32(p + "norm2.weight", L.norm2, D); }
     else { ones(L.norm1, D); ones(L.norm2, D); }
-    to_bf16(p + "attn.q_proj.weight", L.wqkv, (int64_t)D * D);                       // fused [Wq; Wk; Wv]
-    to_bf16(p + "attn.k_proj.weight", L.wqkv + (int64_t)D * D, (int64_t)kvD * D);
+    // fused [Wq; Wk; Wv]; q/k rows pair-interleaved per head so that RoPE pairs share a lane (gemm.hip)
+    to_bf16_rope(p + "attn.q_proj.weight", L.wqkv, D, D);
+    to_bf16_rope(p + "attn.k_proj.weight", L.wqkv + (int64_t)D * D, kvD, D);
     to_bf16(p + "attn.v_proj.weight", L.wqkv + (int64_t)(D + kvD) * D, (int64_t)kvD * D);
     to_bf16(p + "attn.out_proj.weight", L.wo, (int64_t)D * D);
     to_bf16(p + "mlp.0.weight", L.w1, (int64_t)mlp * D);
@@ -270,11 +284,33 @@ extern "C" int jat_model_workspace_bytes(const jat_model* m, int32_t B, int32_t 
 // ---------------------------------------------------------------------------------------------------------
 // forward pieces
 // ---------------------------------------------------------------------------------------------------------
-static int gemm(const jat_model* m, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, int M, int N, int K,
-                int epi, GemmArgs extra, hipStream_t s) {
+// Tile choice by shape (gemm.hip variant table; measured on MI355X, profiles/r01/gemm_variants.md).  What
+// decides is how the tile count quantises onto 256 CUs (one 8-wave block or two 4-wave blocks per CU) and how
+// many bytes are staged per MFMA: 256x160 (224 tiles at M=7168, N=1280: one round) > 128x160 > 256x256 > 128x128.
+static int pick_variant(int M, int N) {
+  auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * (N / bn); };
+  auto eff = [&](long t, int slots) { return (double)t / (double)(((t + slots - 1) / slots) * slots); };
+  int best = 20;                                     // 128x128, always valid (N % 128 == 0)
+  double best_score = 0.80 * eff(tiles(128, 128), 512);
+  if (N % 160 == 0) {
+    // several rounds: two independent blocks per CU overlap one block's epilogue with the other's K loop
+    const double e18 = 0.95 * eff(tiles(128, 160), 512);
+    const double e19 = (tiles(256, 160) > 256 ? 0.85 : 1.00) * eff(tiles(256, 160), 256);
+    if (e18 > best_score) { best = 18; best_score = e18; }
+    if (e19 > best_score) { best = 19; best_score = e19; }
+  }
+  if (N % 256 == 0) {
+    const double e21 = (tiles(256, 256) > 256 ? 0.85 : 1.00) * eff(tiles(256, 256), 256);
+    if (e21 > best_score) { best = 21; best_score = e21; }
+  }
+  return best;
+}
+
+static int gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, int M, int N,
+                int K, int epi, GemmArgs extra, hipStream_t s) {
   GemmArgs a = extra;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
-  int variant = m->gemm_variant;
+  int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N);
   hipError_t e = launch_gemm(a, epi, variant, s);
   if (e != hipSuccess) return fail(JAT_E_HIP, "gemm launch (M=%d N=%d K=%d epi=%d): %s", M, N, K, epi, hipGetErrorString(e));
   return JAT_OK;
@@ -296,7 +332,7 @@ static int time_path(const jat_model* m, const Workspace& w, const float* t, int
 static int adaln_path(const jat_model* m, const bf16_t* t_silu, float* mod, int B, int l0, int nl, hipStream_t s) {
   GemmArgs e{};
   e.out = mod; e.ldo = (int64_t)nl * 6 * m->D; e.bias = m->bada + (int64_t)l0 * 6 * m->D; e.ntok = 1;
-  return gemm(m, t_silu, m->D, m->wada + (int64_t)l0 * 6 * m->D * m->D, m->D, B, nl * 6 * m->D, m->D, EPI_F32, e, s);
+  return gemm(m, G_OTHER, t_silu, m->D, m->wada + (int64_t)l0 * 6 * m->D * m->D, m->D, B, nl * 6 * m->D, m->D, EPI_F32, e, s);
 }
 
 // one DiTBlock_GQA on the residual stream w.x  (jat_audiosr_v3.py:284-308); mod_l = this layer's 6D row of batch 0
@@ -309,7 +345,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     GemmArgs e{};
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = ntok;
     e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
-    JCHK(gemm(m, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
+    JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
   }
   {
     AttnArgs a{};
@@ -321,18 +357,18 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
-    JCHK(gemm(m, w.ao, D, L.wo, D, M, D, D, EPI_RESID, e, s));
+    JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_RESID, e, s));
   }
   KCHK(launch_norm_modulate(w.x, L.norm2, mod_l + 3 * D, mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
     GemmArgs e{};
     e.out = w.hm; e.ldo = m->mlp; e.bias = L.b1; e.ntok = ntok;
-    JCHK(gemm(m, w.xn, D, L.w1, D, M, m->mlp, D, EPI_BF16_GELU, e, s));
+    JCHK(gemm(m, G_FC1, w.xn, D, L.w1, D, M, m->mlp, D, EPI_BF16_GELU, e, s));
   }
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = L.b2; e.gate = mod_l + 5 * D; e.gate_bstride = bstride; e.ntok = ntok;
-    JCHK(gemm(m, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_RESID, e, s));
+    JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_RESID, e, s));
   }
   return JAT_OK;
 }
@@ -355,19 +391,19 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
   {
     GemmArgs e{};
     e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok;
-    JCHK(gemm(m, w.a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16_GELU, e, s));
+    JCHK(gemm(m, G_OTHER, w.a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16_GELU, e, s));
   }
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = m->pe_b2; e.ntok = ntok;
-    JCHK(gemm(m, w.h_patch, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, e, s));
+    JCHK(gemm(m, G_OTHER, w.h_patch, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, e, s));
   }
   for (int l = 0; l < m->depth; ++l) JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s));
   KCHK(launch_norm_modulate(w.x, m->final_norm, nullptr, nullptr, 0, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
     GemmArgs e{};
     e.out = x_pred; e.bias = m->bfinal; e.ntok = ntok; e.C_out = m->Cin; e.T_orig = T;
-    JCHK(gemm(m, w.xn, D, m->wfinal, D, M, m->Fout, D, EPI_UNPATCH, e, s));
+    JCHK(gemm(m, G_OTHER, w.xn, D, m->wfinal, D, M, m->Fout, D, EPI_UNPATCH, e, s));
   }
   return JAT_OK;
 }
@@ -431,7 +467,7 @@ extern "C" int jat_attn_forward(jat_model* m, int32_t layer, const float* x, flo
     GemmArgs e{};
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = N;
     e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
-    JCHK(gemm(m, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
+    JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
   }
   {
     AttnArgs a{};
@@ -443,7 +479,7 @@ extern "C" int jat_attn_forward(jat_model* m, int32_t layer, const float* x, flo
   {
     GemmArgs e{};
     e.out = y; e.ldo = D; e.ntok = N;
-    JCHK(gemm(m, w.ao, D, L.wo, D, M, D, D, EPI_F32, e, s));
+    JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_F32, e, s));
   }
   return JAT_OK;
 }
@@ -618,6 +654,7 @@ extern "C" int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bia
   a.A = A; a.W = W; a.lda = K; a.ldw = K; a.M = M; a.N = N; a.K = K;
   a.out = C; a.ldo = N; a.bias = bias; a.gate = gate; a.gate_bstride = gate_bstride;
   a.ntok = rows_per_batch > 0 ? rows_per_batch : 1;
+  if (const char* d = getenv("JAT_GEMM_DBG")) a.dbg = atoi(d);
   KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
   return JAT_OK;
 }

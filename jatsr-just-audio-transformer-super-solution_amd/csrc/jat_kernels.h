@@ -35,11 +35,13 @@ struct GemmArgs {
   const float* rope_sin;
   // EPI_UNPATCH
   int C_out, T_orig;
+  int dbg;  // profiling aid (bit0: suppress epilogue stores); 0 in production
 };
 
-// variant: 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves
+// variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);
 int gemm_num_variants();
+void gemm_variant_tile(int variant, int* bm, int* bn);
 
 // ---- attention -----------------------------------------------------------------------------------
 struct AttnArgs {
@@ -70,6 +72,9 @@ hipError_t launch_linear_f32(const float* in, const float* W, const float* bias,
                              bf16_t* out_silu_bf16, int B, int N, int K, int act_out, hipStream_t s);
 hipError_t launch_silu_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
 hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
+// fp32 [rows, cols] -> bf16 with the rows of every 64-row head pair-interleaved for in-lane RoPE:
+// out row (h*64 + 2d + e) <- in row (h*64 + d + 32e), e in {0,1}   (rows % 64 == 0)
+hipError_t launch_cast_bf16_rope_rows(const float* in, bf16_t* out, int rows, int cols, hipStream_t s);
 // z += ((u + s(c-u)) - z)/(1-t+1e-5)*dt  (or z = x when t >= 0.999)  (infer_test_v3m2.py:161-179)
 hipError_t launch_cfg_euler(const float* xp, float* z, float cfg_scale, float t, float dt, int use_cfg,
                             int64_t n_per_half, hipStream_t s);
