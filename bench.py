@@ -142,39 +142,32 @@ def main():
                              "tflops": fwd_flops_B / (fwd_ms * 1e-3) / 1e12,
                              "mfma_frac": fwd_flops_B / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
 
-        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -----------
+        # ---- roofline of the dominant kernel (MLP fc1 GEMM: 28 launches per forward, 26 % of the FLOPs), measured
+        # live: the same sampling run replayed eagerly with every fc1 launch bracketed by a HIP event pair on the
+        # launch stream (jat_prof_*); rocprofv3 --kernel-trace --stats of this command must agree (profiles/).
+        per_run_launches = cfg["depth"] * args.num_steps
+        L.check(L.lib().jat_prof_gemm_site(2, per_run_launches))
+        sampler.run(lr, z0, use_graph=False)
+        torch.cuda.synchronize()
+        tot_ms, n_l, fl, var = C.c_double(), C.c_int32(), C.c_double(), C.c_int32()
+        L.check(L.lib().jat_prof_collect(C.byref(tot_ms), C.byref(n_l), C.byref(fl), C.byref(var)))
         Mg = (2 if use_cfg else 1) * B * ((T + 3) // 4)
         Ng, Kg = int(cfg["hidden_size"] * cfg.get("mlp_ratio", 4.0)), cfg["hidden_size"]
-        A = (torch.randn(Mg, Kg, device=dev)).to(torch.bfloat16)
-        W = (torch.randn(Ng, Kg, device=dev) / Kg ** 0.5).to(torch.bfloat16)
-        bias = torch.randn(Ng, device=dev) * 0.05
-        Cout = torch.empty(Mg, Ng, dtype=torch.bfloat16, device=dev)
-        variant = int(os.environ.get("JAT_GEMM_VARIANT", "0"))
-
-        def gemm():
-            L.check(L.lib().jat_k_gemm(L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Cout), Mg, Ng, Kg, 2, None, 0, 1,
-                                       variant, L.stream_ptr()))
-        for _ in range(5):
-            gemm()
-        ng = 50
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(ng):
-            gemm()
-        ev1.record()
-        torch.cuda.synchronize()
-        g_ms = ev0.elapsed_time(ev1) / ng
-        g_flops = 2.0 * Mg * Ng * Kg
+        g_ms = tot_ms.value / max(n_l.value, 1)
+        g_flops = fl.value / max(n_l.value, 1)
         ach = g_flops / (g_ms * 1e-3) / 1e12
-        result["roofline"] = {"kernel": f"gemm_bf16_kernel<EPI_BF16_GELU> (MLP fc1) M={Mg} N={Ng} K={Kg}",
+        result["roofline"] = {"kernel": f"gemm_bf16_kernel<...,EPI_BF16_GELU> tile variant {var.value} (MLP fc1) "
+                                        f"M={Mg} N={Ng} K={Kg}",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                              "flops_per_launch": g_flops, "avg_launch_ms": g_ms}
+                              "flops_per_launch": g_flops, "avg_launch_ms": g_ms, "launches_timed": n_l.value}
 
         # ---- CPU baseline: numpy oracle (port of the reference fp32 CPU forward) on a bounded sample --------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import jat_oracle as O
-            cores = os.cpu_count() or 1
+            from threadpoolctl import threadpool_limits
+            cores = min(os.cpu_count() or 1, 32)     # BLAS threads actually used (more only oversubscribes)
+            threadpool_limits(limits=cores)
             orc = O.OracleModel(cfg, sd, "rms", np.float32)
             Bc = 2
             xs, xc = recipe.make_latents(Bc, C_lat, T, salt=5)

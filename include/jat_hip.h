@@ -130,6 +130,14 @@ int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, ui
 /* fp32 -> bf16 (round-to-nearest-even) */
 int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 
+/* ---- measurement aid (bench.py roofline leg; no reference counterpart) ------------------------------------ */
+/* Bracket every GEMM launch of one call site (0 qkv, 1 out_proj, 2 MLP fc1, 3 MLP fc2, 4 other; -1 = off) with a
+ * HIP event pair on the launch stream, for at most max_launches launches.  Eager calls only. */
+int jat_prof_gemm_site(int32_t site, int32_t max_launches);
+/* Sum of the bracketed launch durations [host ms], their count, algorithmic FLOPs and the tile variant used;
+ * synchronises on the recorded events and switches the bracket off. */
+int jat_prof_collect(double* total_ms, int32_t* launches, double* flops, int32_t* variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,12 +109,12 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
     const int koff = kt * BK;
 #pragma unroll
     for (int j = 0; j < AI; ++j)
-      if (PIPE == 3 || PA % NW == 0 || wave + j * NW < PA)
+      if (PIPE >= 3 || PA % NW == 0 || wave + j * NW < PA)
         __builtin_amdgcn_global_load_lds((const void*)(a_src[j] + koff),
                                          (lds_ptr_t)(sA + min(wave + j * NW, PA - 1) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < BI; ++j)
-      if (PIPE == 3 || PB % NW == 0 || wave + j * NW < PB)
+      if (PIPE >= 3 || PB % NW == 0 || wave + j * NW < PB)
         __builtin_amdgcn_global_load_lds((const void*)(b_src[j] + koff),
                                          (lds_ptr_t)(sB + min(wave + j * NW, PB - 1) * 1024), 16, 0, 0);
   };
@@ -179,6 +179,47 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
       mma(af, wf);
       cur = cur == 2 ? 0 : cur + 1;
     }
+  } else if constexpr (PIPE == 4) {
+    // Ping-pong between the two waves that share a SIMD (waves w and w+4 of an 8-wave block): time is cut into
+    // slots separated by s_barrier; in every slot one half of the block (wave group g = wave>>2, which owns one
+    // M-half of the tile) issues its MFMAs for K-tile t while the other half does its LDS fragment reads for its
+    // next K-tile and issues the DMA for tile t+2, then they swap (MI355X_MICROARCH "Two waves per SIMD";
+    // cdna_hip_programming.md 8-phase template).  3-stage LDS ring; counted vmcnt; raw barriers only.
+    //   group 0: LOAD(t) in slot 2t,   MFMA(t) in slot 2t+1      group 1: one slot later.
+    static_assert(NW == 8, "ping-pong needs two waves per SIMD in one block");
+    constexpr int PW = AI + BI;
+    const int grp = wave >> 2;
+    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---- LOAD slot: fragments of both k-steps of tile kt into registers; DMA for tile kt+2
+      read_frags(a0, w0, cur, coff0);
+      read_frags(a1, w1, cur, coff1);
+      if (kt + 2 < nk) {
+        stage(cur == 0 ? 2 : cur - 1, kt + 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // my pieces of tile kt+1 have landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- MFMA slot
+      __builtin_amdgcn_s_setprio(1);
+      mma(a0, w0);
+      mma(a1, w1);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
   } else {
     // interleave hint: one fragment read, then MPR MFMAs, ... (sched_group_barrier masks: MFMA 0x8, DS read 0x100)
     constexpr int NREAD = TM + TN, NMMA = TM * TN, MPR = NMMA / NREAD;
@@ -407,7 +448,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int LDS = (PIPE == 3 ? 3 : 2) * (BM + BN) * 128;
+  constexpr int LDS = (PIPE >= 3 ? 3 : 2) * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   static bool attr_set = false;
   auto kern = gemm_bf16_kernel<WM, WN, TM, TN, PIPE, CE, EPI>;
@@ -443,6 +484,7 @@ static const int kVariantTile[][2] = {
     {128, 128}, {128, 160}, {256, 160}, {224, 160},  // 11-14: PIPE 2
     {256, 128}, {256, 160}, {256, 128},              // 15-17: PIPE 3 (3-stage ring; 17 = 2x4 waves of 128x32)
     {128, 160}, {256, 160}, {128, 128}, {256, 256},  // 18-21: PIPE 2 + coalesced epilogue
+    {256, 160}, {256, 128},                          // 22-23: PIPE 4 (ping-pong) + coalesced epilogue
 };
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
 void gemm_variant_tile(int variant, int* bm, int* bn) {
@@ -476,6 +518,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 19: return launch_epi<4, 2, 4, 5, 2, 1>(a, epi, s);
     case 20: return launch_epi<2, 2, 4, 4, 2, 1>(a, epi, s);
     case 21: return launch_epi<2, 4, 8, 4, 2, 1>(a, epi, s);
+    case 22: return launch_epi<4, 2, 4, 5, 4, 1>(a, epi, s);
+    case 23: return launch_epi<4, 2, 4, 4, 4, 1>(a, epi, s);
   }
   return hipErrorInvalidValue;
 }

@@ -284,6 +284,13 @@ extern "C" int jat_model_workspace_bytes(const jat_model* m, int32_t B, int32_t 
 // ---------------------------------------------------------------------------------------------------------
 // forward pieces
 // ---------------------------------------------------------------------------------------------------------
+struct GemmProf {
+  int site = -1, n = 0, variant = -1;
+  double flops = 0.0;
+  std::vector<hipEvent_t> ev;
+};
+static GemmProf g_prof;
+
 // Tile choice by shape (gemm.hip variant table; measured on MI355X, profiles/r01/gemm_variants.md).  What
 // decides is how the tile count quantises onto 256 CUs (one 8-wave block or two 4-wave blocks per CU) and how
 // many bytes are staged per MFMA: 256x160 (224 tiles at M=7168, N=1280: one round) > 128x160 > 256x256 > 128x128.
@@ -311,7 +318,17 @@ static int gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, cons
   GemmArgs a = extra;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
   int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N);
+  // measurement aid (bench.py roofline leg): bracket the launches of one call site with HIP events on the
+  // launch stream.  Never active during graph capture (the bench enables it around eager forwards only).
+  const bool timed = g_prof.site == site && g_prof.n < (int)g_prof.ev.size() / 2;
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
   hipError_t e = launch_gemm(a, epi, variant, s);
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
+    g_prof.flops += 2.0 * M * N * K;
+    g_prof.variant = variant;
+    ++g_prof.n;
+  }
   if (e != hipSuccess) return fail(JAT_E_HIP, "gemm launch (M=%d N=%d K=%d epi=%d): %s", M, N, K, epi, hipGetErrorString(e));
   return JAT_OK;
 }
@@ -665,6 +682,31 @@ extern "C" int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint1
   a.B = B; a.N = N; a.Hq = Hq; a.Hkv = Hkv; a.npad = Npad;
   a.scale_log2e = 0.125f * 1.4426950408889634f;
   KCHK(launch_attention(a, (hipStream_t)stream));
+  return JAT_OK;
+}
+extern "C" int jat_prof_gemm_site(int32_t site, int32_t max_launches) {
+  if (site < -1 || site > G_OTHER) return fail(JAT_E_INVALID, "site must be -1 (off) or 0..4");
+  g_prof.site = site; g_prof.n = 0; g_prof.flops = 0.0; g_prof.variant = -1;
+  while ((int)g_prof.ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  return JAT_OK;
+}
+extern "C" int jat_prof_collect(double* total_ms, int32_t* launches, double* flops, int32_t* variant) {
+  double tot = 0.0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    HIPCHK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = g_prof.n;
+  if (flops) *flops = g_prof.flops;
+  if (variant) *variant = g_prof.variant;
+  g_prof.site = -1;
   return JAT_OK;
 }
 extern "C" int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream) {
