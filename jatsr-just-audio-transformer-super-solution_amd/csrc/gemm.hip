@@ -56,8 +56,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 // 4-wave blocks with <= 20 accumulator tiles per wave are meant to run two per CU (2 waves per SIMD): cap the
 // register allocation accordingly (2nd launch-bounds argument = waves per SIMD).
+// PIPE 6 adds 4 DMA-only waves (one per SIMD) to the 8 MFMA waves: 768 threads, three waves per SIMD.
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
-__global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
+__global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
     gemm_bf16_kernel(const GemmArgs p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 64;
   constexpr int NW = WM * WN;
@@ -117,6 +118,21 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
       if (PIPE >= 3 || PB % NW == 0 || wave + j * NW < PB)
         __builtin_amdgcn_global_load_lds((const void*)(b_src[j] + koff),
                                          (lds_ptr_t)(sB + min(wave + j * NW, PB - 1) * 1024), 16, 0, 0);
+  };
+
+  auto stage_a = [&](int st, int kt) {   // A pieces only (PIPE 5), uniform count per wave
+    char* sA = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < AI; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)(a_src[j] + kt * BK),
+                                       (lds_ptr_t)(sA + min(wave + j * NW, PA - 1) * 1024), 16, 0, 0);
+  };
+  auto stage_b = [&](int st, int kt) {   // W pieces only
+    char* sB = smem + st * STAGE + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)(b_src[j] + kt * BK),
+                                       (lds_ptr_t)(sB + min(wave + j * NW, PB - 1) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[TM][TN];
@@ -199,9 +215,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
       // ---- LOAD slot: fragments of both k-steps of tile kt into registers; DMA for tile kt+2
-      read_frags(a0, w0, cur, coff0);
-      read_frags(a1, w1, cur, coff1);
-      if (kt + 2 < nk) {
+      if (!(p.dbg & 4) || kt == 0) {
+        read_frags(a0, w0, cur, coff0);
+        read_frags(a1, w1, cur, coff1);
+      }
+      if (kt + 2 < nk && !(p.dbg & 2)) {
         stage(cur == 0 ? 2 : cur - 1, kt + 2);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // my pieces of tile kt+1 have landed
       } else {
@@ -213,6 +231,119 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
       // ---- MFMA slot
       __builtin_amdgcn_s_setprio(1);
       mma(a0, w0);
+      mma(a1, w1);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (PIPE == 6) {
+    // Wave specialisation: waves 0-7 are the ping-pong MFMA waves of PIPE 4 but never touch global memory in the
+    // K loop; waves 8-11 (one per SIMD) only issue the global->LDS DMA, spread evenly over every slot
+    // (A pieces of tile j+2 in slot 2j, W pieces in slot 2j+1), each completing two slots before its first reader.
+    // The per-CU DMA path moves one 1-KiB piece per ~22 cycles (tools/dma_probe.hip), so 52 pieces per K-tile fit
+    // under the 2 x 40 MFMAs of the two slots only if their issue is continuous instead of bursty.
+    static_assert(NW == 8 && PA % 4 == 0 && PB % 4 == 0, "PIPE 6: 8 MFMA waves + 4 DMA waves");
+    constexpr int NDW = 4, AI6 = PA / NDW, BI6 = PB / NDW;
+    if (wave >= NW) {
+      const int dw = wave - NW;
+      const bf16_t* asrc[AI6];
+      const bf16_t* bsrc[BI6];
+#pragma unroll
+      for (int j = 0; j < AI6; ++j)
+        asrc[j] = p.A + (int64_t)min(m0 + (dw + j * NDW) * 8 + srow, p.M - 1) * p.lda + schunk * 8;
+#pragma unroll
+      for (int j = 0; j < BI6; ++j) bsrc[j] = p.W + (int64_t)(n0 + (dw + j * NDW) * 8 + srow) * p.ldw + schunk * 8;
+      auto issue_a = [&](int st, int kt) {
+#pragma unroll
+        for (int j = 0; j < AI6; ++j)
+          __builtin_amdgcn_global_load_lds((const void*)(asrc[j] + kt * BK),
+                                           (lds_ptr_t)(smem + st * STAGE + (dw + j * NDW) * 1024), 16, 0, 0);
+      };
+      auto issue_b = [&](int st, int kt) {
+#pragma unroll
+        for (int j = 0; j < BI6; ++j)
+          __builtin_amdgcn_global_load_lds((const void*)(bsrc[j] + kt * BK),
+                                           (lds_ptr_t)(smem + st * STAGE + A_BYTES + (dw + j * NDW) * 1024), 16, 0, 0);
+      };
+      issue_a(0, 0);
+      issue_b(0, 0);
+      if (nk > 1) {
+        issue_a(1, 1);
+        issue_b(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI6 + BI6) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // tile 0 visible
+      int st = 2;                    // stage of tile j+2
+      for (int sl = 0; sl <= 2 * nk; ++sl) {
+        const int t = (sl >> 1) + 2;
+        if (t < nk) {
+          if (sl & 1) issue_b(st, t); else issue_a(st, t);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI6 + BI6) : "memory");  // everything older than 2 slots landed
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (sl & 1) st = st == 2 ? 0 : st + 1;
+      }
+      if constexpr (CE && EPI <= EPI_QKV_ROPE) __builtin_amdgcn_s_barrier();  // pairs with the epilogue's barrier
+      return;
+    }
+    const int grp = wave >> 2;
+    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      read_frags(a0, w0, cur, coff0);
+      read_frags(a1, w1, cur, coff1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      mma(a0, w0);
+      mma(a1, w1);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (PIPE == 5) {
+    // Ping-pong as PIPE 4, but the W pieces of tile kt+2 are issued from inside the MFMA slot (between the two
+    // k-steps), so the load slot (fragment reads + A pieces) is no longer the longer of the two slots.
+    static_assert(NW == 8, "ping-pong needs two waves per SIMD in one block");
+    const int grp = wave >> 2;
+    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
+    stage(0, 0);
+    if (nk > 1) stage_a(1, 1);
+    if (nk > 1) stage_b(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nxt2 = cur == 0 ? 2 : cur - 1;
+      read_frags(a0, w0, cur, coff0);
+      read_frags(a1, w1, cur, coff1);
+      if (kt + 2 < nk) {
+        stage_a(nxt2, kt + 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI) : "memory");   // all my pieces of tile kt+1 have landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      mma(a0, w0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) stage_b(nxt2, kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
       mma(a1, w1);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -271,7 +402,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
     constexpr int CPR = TN * 16 / EPC;       // chunks per row
     constexpr int NCH = 32 * CPR / 64;       // chunks per lane per 32-row group
     static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
-    __syncthreads();                          // every wave is done reading the staging buffers
+    __builtin_amdgcn_s_barrier();             // every wave is done reading the staging buffers
     if (p.dbg & 1) return;
     char* wbuf = smem + wave * (32 * RS);
     const int mw0 = m0 + wm * TM * 16;
@@ -329,11 +460,21 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
     static_assert(TM % 2 == 0, "coalesced epilogue walks the wave tile 32 rows at a time");
     constexpr int RS = TN * 32 + 16, CPR = TN * 2, NCH = 32 * CPR / 64;
     static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
     if (p.dbg & 1) return;
     char* wbuf = smem + wave * (32 * RS);
     const int mw0 = m0 + wm * TM * 16;
     const int nqk = p.D + p.kvD;
+    const bool vfast = (p.ntok & 7) == 0;  // 8-token runs stay inside one sample and are 16-B aligned in vt
+    // RoPE angles in registers: a lane needs (pos, d) for ONE row and two frequencies per MFMA tile, so a table
+    // lookup is a 16-cache-line gather per instruction (measured 10 us of a 53 us launch); v_sin/v_cos of
+    // fract(pos * inv_freq / 2pi) costs ~1 us instead.  inv_freq is the reference's fp32 value (:77).
+    float2 invf[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int d0 = (((nw0 + j * 16) & 63) >> 1) + fg * 2;
+      invf[j] = *(const float2*)(p.rope_inv_freq + d0);
+    }
 #pragma unroll
     for (int ig = 0; ig < TM / 2; ++ig) {
 #pragma unroll
@@ -345,17 +486,42 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 20) 
           const int nt = nw0 + j * 16;
           const f32x4 v = acc[2 * ig + ii][j];
           if (nt < nqk) {
-            const int d0 = ((nt & 63) >> 1) + fg * 2;
-            const float2 c = *(const float2*)(p.rope_cos + (int64_t)pos * 32 + d0);
-            const float2 s = *(const float2*)(p.rope_sin + (int64_t)pos * 32 + d0);
+            const float r0 = __builtin_amdgcn_fractf((float)pos * invf[j].x * 0.15915494309189535f);
+            const float r1 = __builtin_amdgcn_fractf((float)pos * invf[j].y * 0.15915494309189535f);
+            const float2 c = float2{__builtin_amdgcn_cosf(r0), __builtin_amdgcn_cosf(r1)};
+            const float2 s = float2{__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1)};
             *(uint2*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 2) =
                 pack4(v[0] * c.x - v[1] * s.x, v[1] * c.x + v[0] * s.x, v[2] * c.y - v[3] * s.y,
                       v[3] * c.y + v[2] * s.y);
-          } else if (mw0 + (2 * ig + ii) * 16 + frow < p.M) {
+          } else if (vfast) {  // v tile: plain bf16 into the slab, transposed out below
+            *(uint2*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 2) = pack4(v[0], v[1], v[2], v[3]);
+          } else if (mw0 + (2 * ig + ii) * 16 + frow < p.M) {  // ragged token count: element-wise transposed store
             const int nv = nt + fg * 4 - nqk;
             bf16_t* dst = p.vt_out + ((int64_t)(b * (p.kvD >> 6) + (nv >> 6)) * 64 + (nv & 63)) * p.npad + pos;
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[(int64_t)r * p.npad] = f2bf(v[r]);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // v tiles: lane = (feature d = lane&15, token group tg = lane>>4): gather 8 consecutive tokens of one
+      // feature down a slab column and store them as ONE 16-B run of vt[b][hv][d][pos..pos+7]
+      if (vfast) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nt = nw0 + j * 16;
+          if (nt >= nqk) {
+            const int mg = mw0 + ig * 32 + fg * 8;  // first of this lane's 8 tokens
+            const char* col = wbuf + (fg * 8) * RS + (j * 16 + frow) * 2;
+            uint4 pk;
+            pk.x = (unsigned)*(const unsigned short*)(col + 0 * RS) | ((unsigned)*(const unsigned short*)(col + 1 * RS) << 16);
+            pk.y = (unsigned)*(const unsigned short*)(col + 2 * RS) | ((unsigned)*(const unsigned short*)(col + 3 * RS) << 16);
+            pk.z = (unsigned)*(const unsigned short*)(col + 4 * RS) | ((unsigned)*(const unsigned short*)(col + 5 * RS) << 16);
+            pk.w = (unsigned)*(const unsigned short*)(col + 6 * RS) | ((unsigned)*(const unsigned short*)(col + 7 * RS) << 16);
+            if (mg < p.M && !(p.dbg & 16)) {  // M % 8 == 0 on this path, so the 8 tokens are valid together
+              const int b = mg / p.ntok, pos = mg - b * p.ntok, nv = nt + frow - nqk;
+              *(uint4*)(p.vt_out + ((int64_t)(b * (p.kvD >> 6) + (nv >> 6)) * 64 + (nv & 63)) * p.npad + pos) = pk;
+            }
           }
         }
       }
@@ -459,7 +625,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   if (a.N % BN != 0 || a.K % 64 != 0 || a.M <= 0) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3((WM * WN + (PIPE == 6 ? 4 : 0)) * 64), LDS, s, a);
   return hipGetLastError();
 }
 
@@ -485,6 +651,8 @@ static const int kVariantTile[][2] = {
     {256, 128}, {256, 160}, {256, 128},              // 15-17: PIPE 3 (3-stage ring; 17 = 2x4 waves of 128x32)
     {128, 160}, {256, 160}, {128, 128}, {256, 256},  // 18-21: PIPE 2 + coalesced epilogue
     {256, 160}, {256, 128},                          // 22-23: PIPE 4 (ping-pong) + coalesced epilogue
+    {256, 160},                                      // 24: PIPE 5 (ping-pong, W pieces issued in the MFMA slot)
+    {256, 160}, {256, 128},                          // 25-26: PIPE 6 (8 MFMA waves + 4 DMA waves)
 };
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
 void gemm_variant_tile(int variant, int* bm, int* bn) {
@@ -520,6 +688,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 21: return launch_epi<2, 4, 8, 4, 2, 1>(a, epi, s);
     case 22: return launch_epi<4, 2, 4, 5, 4, 1>(a, epi, s);
     case 23: return launch_epi<4, 2, 4, 4, 4, 1>(a, epi, s);
+    case 24: return launch_epi<4, 2, 4, 5, 5, 1>(a, epi, s);
+    case 25: return launch_epi<4, 2, 4, 5, 6, 1>(a, epi, s);
+    case 26: return launch_epi<4, 2, 4, 4, 6, 1>(a, epi, s);
   }
   return hipErrorInvalidValue;
 }

@@ -52,7 +52,7 @@ struct jat_model {
   char* blob = nullptr;  // one device allocation holding every packed tensor
   size_t blob_bytes = 0;
   bf16_t *pe_w1, *pe_w2, *wada, *wfinal;
-  float *pe_b1, *pe_b2, *te_w1, *te_b1, *te_w2, *te_b2, *bada, *final_norm, *bfinal, *rope_cos, *rope_sin;
+  float *pe_b1, *pe_b2, *te_w1, *te_b1, *te_w2, *te_b2, *bada, *final_norm, *bfinal, *rope_cos, *rope_sin, *rope_invf;
   std::vector<LayerW> layers;
   // GEMM tile/pipeline variant per call site: qkv, out_proj, fc1, fc2, everything else (gemm.hip table)
   int variants[5] = {-1, -1, -1, -1, -1};  // -1: choose by shape (pick_variant)
@@ -168,7 +168,7 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
   const size_t o_te_w1 = take((size_t)D * D * 4), o_te_b1 = take((size_t)D * 4);
   const size_t o_te_w2 = take((size_t)D * D * 4), o_te_b2 = take((size_t)D * 4);
   const size_t o_bada = take((size_t)depth * 6 * D * 4), o_fn = take((size_t)D * 4), o_bfinal = take((size_t)m->Fout * 4);
-  const size_t o_cos = take((size_t)MAX_LEN * 32 * 4), o_sin = take((size_t)MAX_LEN * 32 * 4);
+  const size_t o_cos = take((size_t)MAX_LEN * 32 * 4), o_sin = take((size_t)MAX_LEN * 32 * 4), o_invf = take(32 * 4);
   if (!m->blob) {
     HIPCHK(hipMalloc((void**)&m->blob, off));
     m->blob_bytes = off;
@@ -180,7 +180,7 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
   m->te_w1 = (float*)(base + o_te_w1); m->te_b1 = (float*)(base + o_te_b1);
   m->te_w2 = (float*)(base + o_te_w2); m->te_b2 = (float*)(base + o_te_b2);
   m->bada = (float*)(base + o_bada); m->final_norm = (float*)(base + o_fn); m->bfinal = (float*)(base + o_bfinal);
-  m->rope_cos = (float*)(base + o_cos); m->rope_sin = (float*)(base + o_sin);
+  m->rope_cos = (float*)(base + o_cos); m->rope_sin = (float*)(base + o_sin); m->rope_invf = (float*)(base + o_invf);
   m->layers.resize(depth);
   for (int l = 0; l < depth; ++l) {
     LayerW& L = m->layers[l];
@@ -256,9 +256,10 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
   // RoPE tables in fp32 exactly as RoPE.__init__ builds them (jat_audiosr_v3.py:77-85); only the first half
   // of `emb = cat([freqs, freqs])` is distinct.
   {
-    std::vector<float> hc((size_t)MAX_LEN * 32), hs((size_t)MAX_LEN * 32);
+    std::vector<float> hc((size_t)MAX_LEN * 32), hs((size_t)MAX_LEN * 32), hf(32);
     for (int i = 0; i < 32; ++i) {
       const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+      hf[i] = inv_freq;
       for (int pos = 0; pos < MAX_LEN; ++pos) {
         const float a = (float)pos * inv_freq;
         hc[(size_t)pos * 32 + i] = cosf(a);
@@ -267,6 +268,7 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
     }
     HIPCHK(hipMemcpyAsync(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->rope_invf, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
   }
   HIPCHK(hipStreamSynchronize(s));
@@ -293,7 +295,8 @@ static GemmProf g_prof;
 
 // Tile choice by shape (gemm.hip variant table; measured on MI355X, profiles/r01/gemm_variants.md).  What
 // decides is how the tile count quantises onto 256 CUs (one 8-wave block or two 4-wave blocks per CU) and how
-// many bytes are staged per MFMA: 256x160 (224 tiles at M=7168, N=1280: one round) > 128x160 > 256x256 > 128x128.
+// many bytes are staged per MFMA: 256x160 with DMA waves (variant 25; 224 tiles at M=7168, N=1280: one round) >
+// 128x160 > 256x256 > 128x128.
 static int pick_variant(int M, int N) {
   auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * (N / bn); };
   auto eff = [&](long t, int slots) { return (double)t / (double)(((t + slots - 1) / slots) * slots); };
@@ -304,7 +307,7 @@ static int pick_variant(int M, int N) {
     const double e18 = 0.95 * eff(tiles(128, 160), 512);
     const double e19 = (tiles(256, 160) > 256 ? 0.85 : 1.00) * eff(tiles(256, 160), 256);
     if (e18 > best_score) { best = 18; best_score = e18; }
-    if (e19 > best_score) { best = 19; best_score = e19; }
+    if (e19 > best_score) { best = 25; best_score = e19; }
   }
   if (N % 256 == 0) {
     const double e21 = (tiles(256, 256) > 256 ? 0.85 : 1.00) * eff(tiles(256, 256), 256);
@@ -318,6 +321,8 @@ static int gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, cons
   GemmArgs a = extra;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
   int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N);
+  static const int dbg_env = getenv("JAT_GEMM_DBG") ? atoi(getenv("JAT_GEMM_DBG")) : 0;  // profiling aid
+  a.dbg = dbg_env;
   // measurement aid (bench.py roofline leg): bracket the launches of one call site with HIP events on the
   // launch stream.  Never active during graph capture (the bench enables it around eager forwards only).
   const bool timed = g_prof.site == site && g_prof.n < (int)g_prof.ev.size() / 2;
@@ -361,7 +366,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   {
     GemmArgs e{};
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = ntok;
-    e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
+    e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin; e.rope_inv_freq = m->rope_invf;
     JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
   }
   {
@@ -483,7 +488,7 @@ extern "C" int jat_attn_forward(jat_model* m, int32_t layer, const float* x, flo
   {
     GemmArgs e{};
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = N;
-    e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
+    e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin; e.rope_inv_freq = m->rope_invf;
     JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
   }
   {

@@ -33,6 +33,7 @@ struct GemmArgs {
   int D, kvD, npad;
   const float* rope_cos; // [max_pos, 32]
   const float* rope_sin;
+  const float* rope_inv_freq;  // [32] fp32: 1/10000^(2i/64), for in-register sin/cos (coalesced epilogue)
   // EPI_UNPATCH
   int C_out, T_orig;
   int dbg;  // profiling aid (bit0: suppress epilogue stores); 0 in production

@@ -108,6 +108,19 @@ def test_attention_module_vs_oracle():
     assert rel_l2(got, ref) < 1e-2
 
 
+def test_attention_rope_accuracy_at_max_length():
+    """RoPE angles are evaluated in registers (fract(pos*inv_freq/2pi) -> v_sin/v_cos); check the longest allowed
+    sequence (N = max_len = 2048, jat_audiosr_v3.py:361), where the fp32 angle is largest, against the fp64 oracle."""
+    cfg = recipe.CONFIGS["micro"]
+    m = build("micro")
+    orc = O.OracleModel(cfg, recipe.make_state_dict(cfg), "rms", np.float64)
+    x = recipe.gaussian("attn_long", (1, 2048, 256), 9)
+    got = m.blocks[0].attn(cuda(x)).cpu().numpy()
+    ref = orc.attention(0, x.astype(np.float64))
+    assert rel_l2(got, ref) < 1e-2
+    assert rel_l2(got[:, -64:], ref[:, -64:]) < 1e-2     # the last positions carry the largest angles
+
+
 def test_standalone_block_and_attention():
     """Modules constructed on their own (reference API jat_audiosr_v3.py:117,257) own a private handle."""
     cfg = recipe.CONFIGS["micro"]
