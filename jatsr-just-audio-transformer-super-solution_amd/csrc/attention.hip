@@ -17,9 +17,11 @@
 //     row bits its permuted read order exercises) — conflict-free ds_read_b128, cdna_hip_programming.md T2.
 // Softmax statistics, the running output and the 1/l normalisation are fp32; P is rounded to bf16 for PV.
 #include "jat_kernels.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __device__ __forceinline__ unsigned short f2bf_a(float f) {
   __bf16 h = (__bf16)f;
@@ -30,11 +32,14 @@ __device__ __forceinline__ unsigned short f2bf_a(float f) {
 // row, so XOR with those (simulated conflict-free for ds_read_b128; `row & 7` would be 2-way here).
 __device__ __forceinline__ int kswz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <int QT>
+template <int QT, int KVB>   // QT 16-row query tiles per wave; KVB keys per LDS block (64 or 128)
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
-  char* sK = smem;
-  char* sV = smem + 8192;
+  constexpr int NKT = KVB / 16;   // 16-key MFMA tiles per block
+  constexpr int NKK = KVB / 32;   // 32-key k-steps of the PV product
+  constexpr int NCH = KVB / 32;   // 16-B staging chunks per thread per operand (KVB*8 chunks / 256 threads)
+  __shared__ __attribute__((aligned(16))) char smem[2 * KVB * 128];
+  char* sK = smem;                // [KVB keys][128 B]
+  char* sV = smem + KVB * 128;    // [64 d][KVB * 2 B]  (row stride KVB*2 bytes, 128-B sub-rows swizzled)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fg = lane >> 4;
@@ -42,6 +47,35 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
   const int hk = h / (p.Hq / p.Hkv);
   const int N = p.N;
   const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+
+  const bf16_t* kbase = p.k + (int64_t)b * N * p.ldk + hk * 64;
+  const bf16_t* vbase = p.vt + ((int64_t)(b * p.Hkv + hk) * 64) * p.npad;
+
+  // register staging (issued one block ahead of the LDS write: T14 split)
+  u32x4 kreg[NCH], vreg[NCH];
+  auto load_regs = [&](int key0) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = tid + 256 * j;
+      const int krow = c >> 3, kch = c & 7;                 // K: KVB rows x 8 chunks
+      kreg[j] = *(const u32x4*)(kbase + (int64_t)min(key0 + krow, N - 1) * p.ldk + kch * 8);
+      const int vrow = c / (KVB / 8), vch = c % (KVB / 8);  // V^T: 64 rows x KVB/8 chunks
+      const int vkey = min(key0 + vch * 8, p.npad - 8);
+      vreg[j] = *(const u32x4*)(vbase + (int64_t)vrow * p.npad + vkey);
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = tid + 256 * j;
+      const int krow = c >> 3, kch = c & 7;
+      *(u32x4*)(sK + krow * 128 + ((kch ^ kswz(krow)) << 4)) = kreg[j];
+      const int vrow = c / (KVB / 8), vch = c % (KVB / 8);
+      // V^T row = 2 (KVB=128) or 1 (KVB=64) sub-rows of 128 B; swizzle the chunk inside its sub-row
+      *(u32x4*)(sV + vrow * (KVB * 2) + (vch >> 3) * 128 + (((vch & 7) ^ (vrow & 7)) << 4)) = vreg[j];
+    }
+  };
+  load_regs(0);
 
   // Q fragments (MFMA B operand): lane holds Q[q0 + qt*16 + (lane&15)][s*32 + 8*(lane>>4) .. +7]
   bf16x8 qf[QT][2];
@@ -63,33 +97,22 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
     for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const bf16_t* kbase = p.k + (int64_t)b * N * p.ldk + hk * 64;
-  const bf16_t* vbase = p.vt + ((int64_t)(b * p.Hkv + hk) * 64) * p.npad;
-
-  const int nkb = (N + 63) >> 6;
+  const int nkb = (N + KVB - 1) / KVB;
   for (int kb = 0; kb < nkb; ++kb) {
-    const int key0 = kb * 64;
+    const int key0 = kb * KVB;
     __syncthreads();  // all waves done reading the previous block
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = tid + 256 * j, row = c >> 3, ch = c & 7;
-      const int dst = row * 128 + ((ch ^ (row & 7)) << 4);        // V^T image: rows read in natural order
-      const int dstk = row * 128 + ((ch ^ kswz(row)) << 4);       // K image: rows read in permuted order
-      const uint4 kv = *(const uint4*)(kbase + (int64_t)min(key0 + row, N - 1) * p.ldk + ch * 8);
-      const uint4 vv = *(const uint4*)(vbase + (int64_t)row * p.npad + key0 + ch * 8);
-      *(uint4*)(sK + dstk) = kv;
-      *(uint4*)(sV + dst) = vv;
-    }
+    write_lds();
     __syncthreads();
+    if (kb + 1 < nkb) load_regs(key0 + KVB);  // next block's loads fly under this block's MFMAs
 
     // ---- S^T = K Q^T ---------------------------------------------------------------------------
-    f32x4 st[QT][4];
+    f32x4 st[QT][NKT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kt = 0; kt < NKT; ++kt) st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       const int r = 32 * (kt >> 1) + 8 * (frow >> 2) + (frow & 3) + 4 * (kt & 1);  // permuted key row
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -100,13 +123,13 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
       }
     }
 
-    // ---- online softmax (per query = per lane column; keys across 16 regs and the 4 lane groups) --
-    bf16x8 pf[QT][2];
+    // ---- online softmax (per query = per lane column; keys across regs and the 4 lane groups) ------
+    bf16x8 pf[QT][NKK];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float mx = -1e30f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
@@ -121,7 +144,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
       m_run[qt] = m_new;
       float sum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pv = exp2f(st[qt][kt][r] - m_new);
@@ -129,12 +152,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
           sum += pv;
         }
       l_run[qt] = l_run[qt] * alpha + sum;
+      if (kb > 0) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        o[qt][dt][0] *= alpha; o[qt][dt][1] *= alpha; o[qt][dt][2] *= alpha; o[qt][dt][3] *= alpha;
+        for (int dt = 0; dt < 4; ++dt) {
+          o[qt][dt][0] *= alpha; o[qt][dt][1] *= alpha; o[qt][dt][2] *= alpha; o[qt][dt][3] *= alpha;
+        }
       }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < NKK; ++kk) {
         bf16x8 f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -147,11 +172,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
 
     // ---- O^T += V^T P^T --------------------------------------------------------------------------
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int d = dt * 16 + frow;
-        const bf16x8 vf = *(const bf16x8*)(sV + d * 128 + (((kk * 4 + fg) ^ (d & 7)) << 4));
+        const int ch = kk * 4 + fg;  // 16-B chunk (8 keys) inside the V^T row
+        const bf16x8 vf = *(const bf16x8*)(sV + d * (KVB * 2) + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], o[qt][dt], 0, 0, 0);
@@ -179,10 +205,166 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
   }
 }
 
+// ---- short-sequence variant (N <= 128, the sampler's N = 128): one workgroup per (batch, KV head) --------------
+// K [128 keys][64] and V^T [64][128 keys] are staged in LDS ONCE and reused by the G = Hq/Hkv query heads that share
+// them (the repeat_interleave of jat_audiosr_v3.py:164-165); no online-softmax state is carried because all keys
+// fit one block.  The next head's Q fragments are prefetched under the current head's MFMAs.
+template <int QT, int NWV>   // NWV waves per block, each owning QT 16-row query tiles (NWV*QT*16 = 128 rows)
+__global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) {
+  constexpr int KVB = 128, NKT = 8, NKK = 4, NT = NWV * 64, NCH = 1024 / NT;
+  static_assert(NWV * QT * 16 == 128, "one block covers 128 query rows");
+  __shared__ __attribute__((aligned(16))) char smem[2 * KVB * 128];
+  char* sK = smem;
+  char* sV = smem + KVB * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int hk = blockIdx.x, b = blockIdx.y;
+  const int G = p.Hq / p.Hkv, N = p.N;
+  const int q0 = wave * (16 * QT);
+  const bf16_t* kbase = p.k + (int64_t)b * N * p.ldk + hk * 64;
+  const bf16_t* vbase = p.vt + ((int64_t)(b * p.Hkv + hk) * 64) * p.npad;
+  {
+    u32x4 kreg[NCH], vreg[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = tid + NT * j;
+      kreg[j] = *(const u32x4*)(kbase + (int64_t)min(c >> 3, N - 1) * p.ldk + (c & 7) * 8);
+      vreg[j] = *(const u32x4*)(vbase + (int64_t)(c >> 4) * p.npad + min((c & 15) * 8, p.npad - 8));
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = tid + NT * j;
+      const int krow = c >> 3, kch = c & 7, vrow = c >> 4, vch = c & 15;
+      *(u32x4*)(sK + krow * 128 + ((kch ^ kswz(krow)) << 4)) = kreg[j];
+      *(u32x4*)(sV + vrow * 256 + (vch >> 3) * 128 + (((vch & 7) ^ (vrow & 7)) << 4)) = vreg[j];
+    }
+  }
+  auto load_q = [&](bf16x8(&qf)[QT][2], int h) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = min(q0 + qt * 16 + frow, N - 1);
+      const bf16_t* qp = p.q + ((int64_t)b * N + q) * p.ldq + h * 64 + fg * 8;
+      qf[qt][0] = *(const bf16x8*)(qp);
+      qf[qt][1] = *(const bf16x8*)(qp + 32);
+    }
+  };
+  bf16x8 qa[QT][2], qb[QT][2];
+  load_q(qa, hk * G);
+  __syncthreads();
+
+  auto head = [&](const bf16x8(&qf)[QT][2], int h) {
+    f32x4 st[QT][NKT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int r = 32 * (kt >> 1) + 8 * (frow >> 2) + (frow & 3) + 4 * (kt & 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(sK + r * 128 + (((s * 4 + fg) ^ kswz(r)) << 4));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], st[qt][kt], 0, 0, 0);
+      }
+    }
+    bf16x8 pf[QT][NKK];
+    float linv[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (N < KVB) {  // wave-uniform: mask the padded keys only when there are any
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r >= N) st[qt][kt][r] = -1e30f;
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        mx = fmaxf(mx, fmaxf(fmaxf(st[qt][kt][0], st[qt][kt][1]), fmaxf(st[qt][kt][2], st[qt][kt][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float nb = -mx * p.scale_log2e;   // scale > 0: max commutes with the scaling
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[qt][kt][r], p.scale_log2e, nb));  // one FMA + v_exp_f32
+          st[qt][kt][r] = pv;
+          sum += pv;
+        }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      linv[qt] = 1.0f / sum;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        bf16x8 f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = (__bf16)st[qt][2 * kk][r];
+          f[4 + r] = (__bf16)st[qt][2 * kk + 1][r];
+        }
+        pf[qt][kk] = f;
+      }
+    }
+    f32x4 o[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + frow, ch = kk * 4 + fg;
+        const bf16x8 vf = *(const bf16x8*)(sV + d * 256 + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], o[qt][dt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = q0 + qt * 16 + frow;
+      if (q < N) {
+        bf16_t* op = p.o + ((int64_t)b * N + q) * p.ldo + h * 64 + fg * 4;
+        const float inv = linv[qt];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 r;
+          r.x = (unsigned)f2bf_a(o[qt][dt][0] * inv) | ((unsigned)f2bf_a(o[qt][dt][1] * inv) << 16);
+          r.y = (unsigned)f2bf_a(o[qt][dt][2] * inv) | ((unsigned)f2bf_a(o[qt][dt][3] * inv) << 16);
+          *(uint2*)(op + dt * 16) = r;
+        }
+      }
+    }
+  };
+  // heads two at a time so that the Q double buffer is addressed statically (rule 20)
+  for (int g = 0; g < G; g += 2) {
+    const int h = hk * G + g;
+    if (g + 1 < G) load_q(qb, h + 1);
+    head(qa, h);
+    if (g + 1 < G) {
+      if (g + 2 < G) load_q(qa, h + 2);
+      head(qb, h + 1);
+    }
+  }
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.N <= 0 || a.B <= 0 || a.Hq % a.Hkv != 0 || a.npad % 64 != 0 || a.npad < a.N) return hipErrorInvalidValue;
   constexpr int QT = 2;
   dim3 grid((a.N + 64 * QT - 1) / (64 * QT), a.Hq, a.B);
-  hipLaunchKernelGGL(attn_fwd_kernel<QT>, grid, dim3(256), 0, s, a);
+  static const int kvb_env = getenv("JAT_ATTN_KVB") ? atoi(getenv("JAT_ATTN_KVB")) : 64;
+  static const int group_env = getenv("JAT_ATTN_GROUP") ? atoi(getenv("JAT_ATTN_GROUP")) : 1;
+  if (group_env && a.N <= 128 && a.npad >= 128) {   // the sampler's shape: K/V staged once per KV head
+    hipLaunchKernelGGL((attn_group_kernel<1, 8>), dim3(a.Hkv, a.B), dim3(512), 0, s, a);
+  } else if (kvb_env == 64 || a.N <= 64) {
+    hipLaunchKernelGGL((attn_fwd_kernel<QT, 64>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_kernel<QT, 128>), grid, dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }

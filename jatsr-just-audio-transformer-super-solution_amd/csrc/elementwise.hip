@@ -2,6 +2,7 @@
 // All of them stream 16 B per lane (cdna_hip_programming.md Guideline 13) and reduce with 64-wide
 // wavefront shuffles; none is GEMM-shaped.
 #include "jat_kernels.h"
+#include <cstdlib>
 
 __device__ __forceinline__ unsigned short f2bf_e(float f) {
   __bf16 h = (__bf16)f;
@@ -84,10 +85,87 @@ __global__ void __launch_bounds__(256) norm_modulate_kernel(const float* __restr
   }
 }
 
+// Persistent variant for the common widths (NCH = D/256 known at compile time): each wave walks rows
+// wave, wave + nwaves, ... and issues the NEXT row's loads before it reduces the current one, so the load
+// latency of a row hides under the previous row's shuffle reduction and stores.
+typedef __attribute__((ext_vector_type(4))) float f32x4_e;
+template <int NCH>
+__global__ void __launch_bounds__(256) norm_modulate_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ scale, int64_t mod_bstride,
+                                                                 bf16_t* __restrict__ y, int M, int ntok, int mode) {
+  constexpr int D = NCH * 256;
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f32x4_e ww[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    ww[c] = (mode == 0 && w) ? *(const f32x4_e*)(w + c * 256 + lane * 4) : f32x4_e{1.f, 1.f, 1.f, 1.f};
+  f32x4_e cur[NCH], nxt[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) cur[c] = *(const f32x4_e*)(x + (int64_t)row * D + c * 256 + lane * 4);
+  while (true) {
+    const int next = row + nwaves;
+    if (next < M) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) nxt[c] = *(const f32x4_e*)(x + (int64_t)next * D + c * 256 + lane * 4);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      s1 += cur[c][0] + cur[c][1] + cur[c][2] + cur[c][3];
+      s2 += cur[c][0] * cur[c][0] + cur[c][1] * cur[c][1] + cur[c][2] * cur[c][2] + cur[c][3] * cur[c][3];
+    }
+    float mu = 0.f, rstd = 1.f;
+    if (mode == 0) {
+      rstd = rsqrtf(wave_sum(s2) / (float)D + 1e-6f);
+    } else if (mode == 1) {
+      mu = wave_sum(s1) / (float)D;
+      float var = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) var += (cur[c][e] - mu) * (cur[c][e] - mu);
+      rstd = rsqrtf(wave_sum(var) / (float)D + 1e-6f);
+    }
+    const int b = row / ntok;
+    const float* sh = shift ? shift + (int64_t)b * mod_bstride + lane * 4 : nullptr;
+    const float* sc = scale ? scale + (int64_t)b * mod_bstride + lane * 4 : nullptr;
+    bf16_t* yr = y + (int64_t)row * D + lane * 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      f32x4_e t = (cur[c] - mu) * rstd * ww[c];
+      if (sc) {
+        const f32x4_e a = *(const f32x4_e*)(sc + c * 256);
+        const f32x4_e s = *(const f32x4_e*)(sh + c * 256);
+        t = t * (1.f + a) + s;
+      }
+      *(uint2*)(yr + c * 256) = pack4_e(t[0], t[1], t[2], t[3]);
+    }
+    if (next >= M) break;
+    row = next;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
+  }
+}
+
 hipError_t launch_norm_modulate(const float* x, const float* w, const float* shift, const float* scale,
                                 int64_t mod_bstride, bf16_t* y, int M, int D, int ntok, int mode, hipStream_t s) {
   if (D % 256 != 0 || D > 2048 || M <= 0 || ntok <= 0) return hipErrorInvalidValue;
   if ((shift == nullptr) != (scale == nullptr)) return hipErrorInvalidValue;
+  static const int rows_per_wave = getenv("JAT_NORM_RPW") ? atoi(getenv("JAT_NORM_RPW")) : 4;
+  if (rows_per_wave > 0 && (D == 1280 || D == 512 || D == 256)) {
+    const int blocks = ((M + 3) / 4 + rows_per_wave - 1) / rows_per_wave;
+    if (D == 1280)
+      hipLaunchKernelGGL(norm_modulate_rows_kernel<5>, dim3(blocks), dim3(256), 0, s, x, w, shift, scale, mod_bstride, y, M, ntok, mode);
+    else if (D == 512)
+      hipLaunchKernelGGL(norm_modulate_rows_kernel<2>, dim3(blocks), dim3(256), 0, s, x, w, shift, scale, mod_bstride, y, M, ntok, mode);
+    else
+      hipLaunchKernelGGL(norm_modulate_rows_kernel<1>, dim3(blocks), dim3(256), 0, s, x, w, shift, scale, mod_bstride, y, M, ntok, mode);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(norm_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, shift, scale, mod_bstride, y, M,
                      D, ntok, mode);
   return hipGetLastError();

@@ -408,7 +408,10 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
     mod = w.mod;
     mod_bstride = (int64_t)m->depth * 6 * D;
   }
-  HIPCHK(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));  // zero the key padding of V^T once per forward
+  // The key padding of V^T must be zero (0 * garbage could be NaN).  Nothing ever writes the padding, so the
+  // sampler zeroes its private buffer once at creation (mod != nullptr path) and only the generic entry point,
+  // whose workspace belongs to the caller, clears it per call.
+  if (t) HIPCHK(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
   KCHK(launch_patchify(x_t, x_cond, w.a_patch, B, B_src, cond_zero_from, m->Cin, m->Cc, T, ntok, s));
   {
     GemmArgs e{};
@@ -599,6 +602,7 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
     if (hipStreamSynchronize(s) != hipSuccess) return bail(fail(JAT_E_HIP, "sync after table build"));
   }
   sp->w = carve(m, sp->Bf, ntok, (char*)sp->ws);
+  if (hipMemsetAsync(sp->w.vt, 0, sp->w.vt_bytes, s) != hipSuccess) return bail(fail(JAT_E_HIP, "memset vt"));
 
   // one eager pass first: sets every kernel's function attributes outside of capture and validates launches
   if (hipMemsetAsync(sp->z, 0, lat, s) != hipSuccess || hipMemsetAsync(sp->lr, 0, lat, s) != hipSuccess)

@@ -200,6 +200,19 @@ def test_sampler_vs_reference_golden(name):
     assert torch.equal(out3, out_g)
 
 
+def test_graph_replay_is_deterministic():
+    """Race screen: the captured 50-step graph replayed 25 times on the same inputs must give bit-identical
+    results (a memset node inside the captured chain used to race with its neighbours on short kernels: the
+    V^T padding is now cleared once at sampler creation, outside the graph)."""
+    m = build("tiny")
+    lr = cuda(recipe.gaussian("lr_latent", (1, 1024, 64), 200))
+    z0 = cuda(recipe.gaussian("z0", (1, 1024, 64), 201))
+    ref = jatsr_amd.flow_matching_sample(m, lr, num_steps=50, cfg_scale=3.0, verbose=False, z0=z0, use_graph=False)
+    bad = sum(int(not torch.equal(jatsr_amd.flow_matching_sample(m, lr, num_steps=50, cfg_scale=3.0, verbose=False,
+                                                                 z0=z0), ref)) for _ in range(25))
+    assert bad == 0
+
+
 def test_sampler_one_step_matches_forward_plus_euler():
     """One sampler step == model forward on the CFG double batch + jat_cfg_euler_step (infer_test_v3m2.py:154-179)."""
     m = build("micro")
