@@ -330,6 +330,33 @@ hipError_t launch_cast_bf16_rope_rows(const float* in, bf16_t* out, int rows, in
   return hipGetLastError();
 }
 
+// ---- norm-folding table helpers (sampler creation only) ---------------------------------------------------------
+__global__ void fold_scale_kernel(const float* __restrict__ w, const float* __restrict__ scale, int64_t in_stride,
+                                  float* __restrict__ out, int64_t out_stride, int rows, int cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, k = i - r * cols;
+  out[(int64_t)r * out_stride + k] = w[k] * (1.0f + scale[(int64_t)r * in_stride + k]);
+}
+hipError_t launch_fold_scale(const float* w, const float* scale, int64_t in_stride, float* out, int64_t out_stride,
+                             int rows, int cols, hipStream_t s) {
+  const int n = rows * cols;
+  hipLaunchKernelGGL(fold_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, scale, in_stride, out, out_stride, rows, cols);
+  return hipGetLastError();
+}
+__global__ void gather_cast_rows_kernel(const float* __restrict__ in, int64_t in_stride, bf16_t* __restrict__ out, int rows,
+                                        int cols) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, k = i - r * cols;
+  out[(int64_t)r * cols + k] = f2bf_e(in[(int64_t)r * in_stride + k]);
+}
+hipError_t launch_gather_cast_rows(const float* in, int64_t in_stride, bf16_t* out, int rows, int cols, hipStream_t s) {
+  const int n = rows * cols;
+  hipLaunchKernelGGL(gather_cast_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, in_stride, out, rows, cols);
+  return hipGetLastError();
+}
+
 // ---- CFG combine + Euler step (infer_test_v3m2.py:161-179) ----------------------------------------------
 // x = u + s (c - u);  z += (x - z) / (1 - t + 1e-5) * dt   (t < 0.999)   |   z = x   (otherwise)
 // The branch depends only on the host-side schedule, so it is a kernel argument, not a device read.

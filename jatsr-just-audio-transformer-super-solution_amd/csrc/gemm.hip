@@ -54,6 +54,51 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
+// consumer side of the norm folding: 1/rms of row m of the A operand from the producer's partial sums (fixed order)
+// The partials of a wave tile's rows are one contiguous block of part[M][np]: read it lane-linear (16 B per lane, whole
+// cache lines) and finish the row sums with shuffles instead of gathering np floats per row (a 16-line gather per
+// instruction cost ~10 us per launch).  np in {4, 8, 16}; result: rstd[i] for row i*16 + (lane&15).
+template <int TM>
+__device__ __forceinline__ void rows_rstd(const GemmArgs& p, int row0, int lane, float (&rstd)[TM]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rstd[i] = 1.0f;
+  if (!p.rs_part) return;
+  const int lpr = p.rs_np >> 2;                    // lanes per row (1, 2 or 4)
+  const int rpi = 64 / lpr;                        // rows per 64-lane load
+  const int frow = lane & 15;
+  const float invk = 1.0f / (float)p.K;
+  float sums[TM];                                  // sums[t]: row sum held by the lpr lanes of row t*rpi + lane/lpr
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    sums[t] = 0.f;
+    if (t * rpi < TM * 16) {
+      const int row = min(row0 + t * rpi + lane / lpr, p.M - 1);
+      const float4 v = *(const float4*)(p.rs_part + (int64_t)row * p.rs_np + (lane % lpr) * 4);
+      float sq = (v.x + v.y) + (v.z + v.w);
+      if (lpr >= 2) sq += __shfl_xor(sq, 1);
+      if (lpr >= 4) sq += __shfl_xor(sq, 2);
+      sums[t] = sq;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = i * 16 + frow;                   // this lane's row inside the wave tile
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {                 // static register index, wave-uniform select
+      const float cand = __shfl(sums[t], (r % rpi) * lpr);
+      if (r / rpi == t) sq = cand;
+    }
+    rstd[i] = rsqrtf(sq * invk + 1e-6f);
+  }
+}
+// producer side: A'[m][n..n+3] = bf16(x * g[b][n..n+3]); this chunk's sum of squares goes back into its slab slot
+__device__ __forceinline__ void fold_emit(const GemmArgs& p, char* slot, float4 x, int m, int n, int b) {
+  const float4 g = *(const float4*)(p.fold_g + (int64_t)b * p.fold_g_bstride + n);
+  *(uint2*)(p.fold_out + (int64_t)m * p.ldo + n) = pack4(x.x * g.x, x.y * g.y, x.z * g.z, x.w * g.w);
+  *(float*)slot = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+}
+
 // 4-wave blocks with <= 20 accumulator tiles per wave are meant to run two per CU (2 waves per SIMD): cap the
 // register allocation accordingly (2nd launch-bounds argument = waves per SIMD).
 // PIPE 6 adds 4 DMA-only waves (one per SIMD) to the 8 MFMA waves: 768 threads, three waves per SIMD.
@@ -161,6 +206,10 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
   };
+
+  // norm folding, consumer side: 1/rms of this lane's TM rows, loaded before the K loop so the latency is hidden
+  float rstd_rows[TM];
+  rows_rstd<TM>(p, m0 + wm * TM * 16, lane, rstd_rows);
 
   const int nk = p.K / BK;
   if constexpr (PIPE == 0) {
@@ -410,13 +459,14 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] const bool fold = OUT32 && p.fold_out != nullptr;
 #pragma unroll
     for (int ig = 0; ig < TM / 2; ++ig) {
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          f32x4 v = acc[2 * ig + ii][j];
+          f32x4 v = acc[2 * ig + ii][j] * rstd_rows[2 * ig + ii];
           v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w;
           char* dst = wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * EB;
           if constexpr (OUT32) {
@@ -442,14 +492,35 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
             x.x += g.x * __uint_as_float(raw.x); x.y += g.y * __uint_as_float(raw.y);
             x.z += g.z * __uint_as_float(raw.z); x.w += g.w * __uint_as_float(raw.w);
             *xp = x;
+            if (fold) fold_emit(p, wbuf + row * RS + cc * 16, x, m, n, b);
           } else if constexpr (EPI == EPI_F32) {
             *(uint4*)((float*)p.out + (int64_t)m * p.ldo + n) = raw;
+            if (fold)
+              fold_emit(p, wbuf + row * RS + cc * 16,
+                        float4{__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)},
+                        m, n, m / p.ntok);
           } else {
             *(uint4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = raw;
           }
+        } else if (OUT32 && fold) {
+          *(float*)(wbuf + row * RS + cc * 16) = 0.f;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (OUT32) {
+        // row partial sums of x_new^2 over this wave's columns, summed in a fixed order by one lane per row
+        if (fold) {  // two lanes per row, fixed order: lane 2r sums the even chunks' half, lane 2r+1 the other
+          constexpr int HALF = CPR / 2;
+          const int r = lane >> 1, h = lane & 1;
+          float sq = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < HALF; ++cc) sq += *(const float*)(wbuf + r * RS + (h * HALF + cc) * 16);
+          sq += __shfl_xor(sq, 1);
+          const int m = mw0 + ig * 32 + r;
+          if (h == 0 && m < p.M) p.fold_part[(int64_t)m * p.fold_np + nw0 / (TN * 16)] = sq;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
     return;
   }
@@ -475,6 +546,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       const int d0 = (((nw0 + j * 16) & 63) >> 1) + fg * 2;
       invf[j] = *(const float2*)(p.rope_inv_freq + d0);
     }
+
 #pragma unroll
     for (int ig = 0; ig < TM / 2; ++ig) {
 #pragma unroll
@@ -484,7 +556,11 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int nt = nw0 + j * 16;
-          const f32x4 v = acc[2 * ig + ii][j];
+          f32x4 v = acc[2 * ig + ii][j] * rstd_rows[2 * ig + ii];
+          if (p.bias) {
+            const float4 bq = *(const float4*)(p.bias + nt + fg * 4);
+            v[0] += bq.x; v[1] += bq.y; v[2] += bq.z; v[3] += bq.w;
+          }
           if (nt < nqk) {
             const float r0 = __builtin_amdgcn_fractf((float)pos * invf[j].x * 0.15915494309189535f);
             const float r1 = __builtin_amdgcn_fractf((float)pos * invf[j].y * 0.15915494309189535f);
@@ -551,11 +627,12 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       b = m / p.ntok;
       pos = m - b * p.ntok;
     }
+    const float rstd_d = rstd_rows[i];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nt = nw0 + j * 16;          // wave-uniform first column of this 16-wide MFMA tile
       const int n = nt + fg * 4;
-      f32x4 v = acc[i][j];
+      f32x4 v = acc[i][j] * rstd_d;
       if ((p.dbg & 1) && v[0] != 12345.678f) continue;
       if constexpr (EPI == EPI_QKV_ROPE) {
         // Wq / Wk rows are packed pair-interleaved per head (position 2d <- feature d, 2d+1 <- feature d+32),
@@ -653,7 +730,12 @@ static const int kVariantTile[][2] = {
     {256, 160}, {256, 128},                          // 22-23: PIPE 4 (ping-pong) + coalesced epilogue
     {256, 160},                                      // 24: PIPE 5 (ping-pong, W pieces issued in the MFMA slot)
     {256, 160}, {256, 128},                          // 25-26: PIPE 6 (8 MFMA waves + 4 DMA waves)
+    {64, 160}, {64, 128},                            // 27-28: small-M tiles (PIPE 2 + coalesced epilogue)
 };
+static const int kVariantWaveN[] = {64, 64, 64, 64, 80, 80, 64, 64, 80, 112, 32, 64, 80, 80, 80, 64, 80, 32,
+                                    80, 80, 64, 64, 80, 64, 80, 80, 64, 80, 64};
+int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
+bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
 void gemm_variant_tile(int variant, int* bm, int* bn) {
   *bm = kVariantTile[variant][0];
@@ -662,7 +744,7 @@ void gemm_variant_tile(int variant, int* bm, int* bn) {
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
   if (variant < 0 || variant >= gemm_num_variants()) return hipErrorInvalidValue;
-  if (a.N % kVariantTile[variant][1] != 0) variant = (a.N % 128 == 0) ? 3 : 10;  // always-valid fallbacks
+  if (a.N % kVariantTile[variant][1] != 0) variant = (a.N % 128 == 0) ? 20 : 10;  // always-valid fallbacks
   switch (variant) {
     case 0: return launch_epi<2, 2, 4, 4, 0>(a, epi, s);
     case 1: return launch_epi<4, 2, 4, 4, 0>(a, epi, s);
@@ -691,6 +773,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 24: return launch_epi<4, 2, 4, 5, 5, 1>(a, epi, s);
     case 25: return launch_epi<4, 2, 4, 5, 6, 1>(a, epi, s);
     case 26: return launch_epi<4, 2, 4, 4, 6, 1>(a, epi, s);
+    case 27: return launch_epi<2, 2, 2, 5, 2, 1>(a, epi, s);
+    case 28: return launch_epi<2, 2, 2, 4, 2, 1>(a, epi, s);
   }
   return hipErrorInvalidValue;
 }

@@ -56,13 +56,14 @@ struct jat_model {
   std::vector<LayerW> layers;
   // GEMM tile/pipeline variant per call site: qkv, out_proj, fc1, fc2, everything else (gemm.hip table)
   int variants[5] = {-1, -1, -1, -1, -1};  // -1: choose by shape (pick_variant)
+  mutable int last_fold_np = 0;            // partial-sum slots per row written by the latest folding producer
 };
 enum { G_QKV = 0, G_OUT = 1, G_FC1 = 2, G_FC2 = 3, G_OTHER = 4 };
 
 // workspace carve-up for a forward over `B` batch rows of `ntok` tokens
 struct Workspace {
   bf16_t *a_patch, *h_patch, *xn, *q, *k, *vt, *ao, *hm, *t_silu;
-  float *x, *mod, *e_sin, *t_h, *t_emb;
+  float *x, *mod, *e_sin, *t_h, *t_emb, *part;
   int npad;
   size_t vt_bytes, total;
 };
@@ -92,6 +93,7 @@ static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
   w.t_h = (float*)take((size_t)B * m->D * 4);
   w.t_emb = (float*)take((size_t)B * m->D * 4);
   w.t_silu = (bf16_t*)take((size_t)B * m->D * 2);
+  w.part = (float*)take(M * 32 * 4);  // row partial sums of x^2 (norm folding), <= 32 wave column tiles
   w.total = off;
   return w;
 }
@@ -298,29 +300,42 @@ static GemmProf g_prof;
 // many bytes are staged per MFMA: 256x160 with DMA waves (variant 25; 224 tiles at M=7168, N=1280: one round) >
 // 128x160 > 256x256 > 128x128.
 static int pick_variant(int M, int N) {
-  auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * (N / bn); };
-  auto eff = [&](long t, int slots) { return (double)t / (double)(((t + slots - 1) / slots) * slots); };
-  int best = 20;                                     // 128x128, always valid (N % 128 == 0)
-  double best_score = 0.80 * eff(tiles(128, 128), 512);
-  if (N % 160 == 0) {
-    // several rounds: two independent blocks per CU overlap one block's epilogue with the other's K loop
-    const double e18 = 0.95 * eff(tiles(128, 160), 512);
-    const double e19 = (tiles(256, 160) > 256 ? 0.85 : 1.00) * eff(tiles(256, 160), 256);
-    if (e18 > best_score) { best = 18; best_score = e18; }
-    if (e19 > best_score) { best = 25; best_score = e19; }
-  }
-  if (N % 256 == 0) {
-    const double e21 = (tiles(256, 256) > 256 ? 0.85 : 1.00) * eff(tiles(256, 256), 256);
-    if (e21 > best_score) { best = 21; best_score = e21; }
+  // score = in-tile efficiency factor x tile-quantisation efficiency on the slots the variant occupies
+  // (256 CUs x 1 eight/twelve-wave block, or x 2 four-wave blocks); factors calibrated on the measured block GEMMs
+  // at M = 7168 and M = 3584 (profiles/r01/gemm_variants_*.log).  Multi-round 1-block-per-CU variants pay 15 %:
+  // their prologue/epilogue is not overlapped by a co-resident block.
+  struct Cand { int id, bm, bn, slots; double f; };
+  static const Cand cands[] = {
+      {20, 128, 128, 512, 0.80}, {18, 128, 160, 512, 0.95}, {25, 256, 160, 256, 1.00},
+      {26, 256, 128, 256, 0.90}, {21, 256, 256, 256, 1.00}, {27, 64, 160, 512, 0.60},
+  };
+  int best = 20;
+  double best_score = -1.0;
+  for (const Cand& c : cands) {
+    if (N % c.bn != 0) continue;
+    const long t = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+    const long rounds = (t + c.slots - 1) / c.slots;
+    double score = c.f * (double)t / (double)(rounds * c.slots);
+    if (c.slots == 256 && rounds > 1) score *= 0.85;
+    if (score > best_score) { best_score = score; best = c.id; }
   }
   return best;
 }
+
+static int kTileN(int variant) { int bm, bn; gemm_variant_tile(variant, &bm, &bn); return bn; }
 
 static int gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, int M, int N,
                 int K, int epi, GemmArgs extra, hipStream_t s) {
   GemmArgs a = extra;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
   int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N);
+  if ((a.fold_out || a.rs_part) && !gemm_variant_coalesced(variant)) variant = 20;  // folding lives in the CE epilogues
+  if (N % kTileN(variant) != 0) variant = 20;  // 128 x 128, always valid
+  if (a.fold_out) { a.fold_np = N / gemm_variant_wave_n(variant); m->last_fold_np = a.fold_np; }
+  if (a.rs_part) a.rs_np = m->last_fold_np;
+  static const int fold_dbg = getenv("JAT_FOLD_NORM") ? atoi(getenv("JAT_FOLD_NORM")) : 0;  // 2/3: timing ablations
+  if (fold_dbg == 2) a.rs_part = nullptr;
+  if (fold_dbg == 3) a.fold_out = nullptr;
   static const int dbg_env = getenv("JAT_GEMM_DBG") ? atoi(getenv("JAT_GEMM_DBG")) : 0;  // profiling aid
   a.dbg = dbg_env;
   // measurement aid (bench.py roofline leg): bracket the launches of one call site with HIP events on the
@@ -357,17 +372,26 @@ static int adaln_path(const jat_model* m, const bf16_t* t_silu, float* mod, int 
   return gemm(m, G_OTHER, t_silu, m->D, m->wada + (int64_t)l0 * 6 * m->D * m->D, m->D, B, nl * 6 * m->D, m->D, EPI_F32, e, s);
 }
 
+// Norm folding (sampler path, RMSNorm only): per-step tables built once at jat_sampler_create.
+//   g     [depth][2][D]   w_norm * (1 + scale)   for norm1 / norm2 of every layer
+//   bq    [depth][D+2kvD] shift_msa @ Wqkv^T                    (added after the row rescale in the QKV epilogue)
+//   bf    [depth][mlp]    shift_mlp @ W1^T + b1
+struct Fold {
+  const float *g, *bq, *bf, *g_final;
+};
+
 // one DiTBlock_GQA on the residual stream w.x  (jat_audiosr_v3.py:284-308); mod_l = this layer's 6D row of batch 0
 static int run_block(const jat_model* m, const Workspace& w, int l, int B, int ntok, const float* mod_l,
-                     int64_t bstride, hipStream_t s) {
-  const int D = m->D, M = B * ntok;
+                     int64_t bstride, hipStream_t s, const Fold* f = nullptr) {
+  const int D = m->D, M = B * ntok, Nqkv = D + 2 * m->kvD;
   const LayerW& L = m->layers[l];
-  KCHK(launch_norm_modulate(w.x, L.norm1, mod_l + 0 * D, mod_l + 1 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  if (!f) KCHK(launch_norm_modulate(w.x, L.norm1, mod_l + 0 * D, mod_l + 1 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
     GemmArgs e{};
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = ntok;
     e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin; e.rope_inv_freq = m->rope_invf;
-    JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, D + 2 * m->kvD, D, EPI_QKV_ROPE, e, s));
+    if (f) { e.rs_part = w.part; e.bias = f->bq + (int64_t)l * Nqkv; }
+    JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, Nqkv, D, EPI_QKV_ROPE, e, s));
   }
   {
     AttnArgs a{};
@@ -379,17 +403,23 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
+    if (f) { e.fold_out = w.xn; e.fold_g = f->g + ((int64_t)l * 2 + 1) * D; e.fold_part = w.part; }
     JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_RESID, e, s));
   }
-  KCHK(launch_norm_modulate(w.x, L.norm2, mod_l + 3 * D, mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  if (!f) KCHK(launch_norm_modulate(w.x, L.norm2, mod_l + 3 * D, mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
     GemmArgs e{};
     e.out = w.hm; e.ldo = m->mlp; e.bias = L.b1; e.ntok = ntok;
+    if (f) { e.rs_part = w.part; e.bias = f->bf + (int64_t)l * m->mlp; }
     JCHK(gemm(m, G_FC1, w.xn, D, L.w1, D, M, m->mlp, D, EPI_BF16_GELU, e, s));
   }
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = L.b2; e.gate = mod_l + 5 * D; e.gate_bstride = bstride; e.ntok = ntok;
+    if (f) {  // feeds the next layer's norm1, or the final norm
+      e.fold_out = w.xn; e.fold_part = w.part;
+      e.fold_g = (l + 1 < m->depth) ? f->g + ((int64_t)(l + 1) * 2) * D : f->g_final;
+    }
     JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_RESID, e, s));
   }
   return JAT_OK;
@@ -400,7 +430,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
 // without materialising the concatenations.  mod == nullptr: compute the modulation from t [B].
 static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t, int B_src, const float* x_cond,
                         int cond_zero_from, const float* t, const float* mod, int64_t mod_bstride, float* x_pred,
-                        int B, int T, hipStream_t s) {
+                        int B, int T, hipStream_t s, const Fold* f = nullptr) {
   const int ntok = (T + 3) / 4, M = B * ntok, D = m->D;
   if (!mod) {
     JCHK(time_path(m, w, t, B, s));
@@ -421,13 +451,15 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = m->pe_b2; e.ntok = ntok;
+    if (f) { e.fold_out = w.xn; e.fold_g = f->g; e.fold_part = w.part; }
     JCHK(gemm(m, G_OTHER, w.h_patch, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, e, s));
   }
-  for (int l = 0; l < m->depth; ++l) JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s));
-  KCHK(launch_norm_modulate(w.x, m->final_norm, nullptr, nullptr, 0, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  for (int l = 0; l < m->depth; ++l) JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s, f));
+  if (!f) KCHK(launch_norm_modulate(w.x, m->final_norm, nullptr, nullptr, 0, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
     GemmArgs e{};
     e.out = x_pred; e.bias = m->bfinal; e.ntok = ntok; e.C_out = m->Cin; e.T_orig = T;
+    if (f) e.rs_part = w.part;
     JCHK(gemm(m, G_OTHER, w.xn, D, m->wfinal, D, M, m->Fout, D, EPI_UNPATCH, e, s));
   }
   return JAT_OK;
@@ -520,6 +552,8 @@ struct jat_sampler {
   std::vector<float> ts;  // [host] linspace(0,1,steps+1)
   char* blob = nullptr;   // private device allocation
   float *z, *lr, *xpred, *mod_table, *ts_dev;
+  float *tab_g = nullptr, *tab_bq = nullptr, *tab_bf = nullptr;  // norm-folding tables (RMSNorm models)
+  bool folded = false;
   void* ws;
   size_t ws_bytes;
   Workspace w;
@@ -543,8 +577,15 @@ static int sampler_steps(jat_sampler* sp, hipStream_t s) {
   const int64_t row = (int64_t)m->depth * 6 * m->D;
   for (int i = 0; i < sp->steps; ++i) {
     const float t_curr = sp->ts[i], dt = sp->ts[i + 1] - sp->ts[i];
+    Fold f{};
+    if (sp->folded) {
+      f.g = sp->tab_g + (size_t)i * m->depth * 2 * m->D;
+      f.bq = sp->tab_bq + (size_t)i * m->depth * (m->D + 2 * m->kvD);
+      f.bf = sp->tab_bf + (size_t)i * m->depth * m->mlp;
+      f.g_final = m->final_norm;
+    }
     JCHK(forward_impl(m, sp->w, sp->z, sp->B, sp->lr, sp->B, nullptr, sp->mod_table + i * row, 0, sp->xpred, sp->Bf,
-                      sp->T, s));
+                      sp->T, s, sp->folded ? &f : nullptr));
     KCHK(launch_cfg_euler(sp->xpred, sp->z, sp->cfg_scale, t_curr, dt, sp->use_cfg ? 1 : 0, n_half, s));
   }
   return JAT_OK;
@@ -580,11 +621,25 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
   const size_t o_z = take(lat), o_lr = take(lat), o_xp = take((size_t)sp->Bf * m->Cin * T * 4);
   const size_t o_tab = take((size_t)steps * row * 4), o_ts = take((size_t)steps * 4), o_ws = take(ws_bytes);
+  const int Nqkv = m->D + 2 * m->kvD;
+  // Norm folding is implemented and parity-tested but measured NEUTRAL on MI355X (455 vs 452 ms per run: the two norm
+  // kernels it removes, 26 us per layer, are paid back by +8 us on each producer and consumer GEMM epilogue), so it
+  // is off by default; JAT_FOLD_NORM=1 enables it (DESIGN.md "what was tried").
+  const int fold_env = getenv("JAT_FOLD_NORM") ? atoi(getenv("JAT_FOLD_NORM")) : 0;  // read per sampler
+  {  // the consumer side reads the row partials lane-linear: needs 4, 8 or 16 slots per row
+    const int np = m->D / gemm_variant_wave_n(m->variants[G_OUT] >= 0 ? m->variants[G_OUT] : pick_variant(sp->Bf * ntok, m->D));
+    sp->folded = fold_env > 0 && m->cfg.norm_mode == JAT_NORM_RMS_W && (np == 4 || np == 8 || np == 16) &&
+                 m->variants[G_OUT] == m->variants[G_FC2] && m->variants[G_OUT] == m->variants[G_OTHER];
+  }
+  const size_t o_g = take((size_t)steps * m->depth * 2 * m->D * 4), o_bq = take((size_t)steps * m->depth * Nqkv * 4);
+  const size_t o_bf = take((size_t)steps * m->depth * m->mlp * 4), o_sh = take((size_t)steps * m->D * 2);
   hipError_t e = hipMalloc((void**)&sp->blob, off);
   if (e != hipSuccess) { delete sp; return fail(JAT_E_HIP, "hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
   sp->z = (float*)(sp->blob + o_z); sp->lr = (float*)(sp->blob + o_lr); sp->xpred = (float*)(sp->blob + o_xp);
   sp->mod_table = (float*)(sp->blob + o_tab); sp->ts_dev = (float*)(sp->blob + o_ts);
   sp->ws = sp->blob + o_ws; sp->ws_bytes = ws_bytes;
+  sp->tab_g = (float*)(sp->blob + o_g); sp->tab_bq = (float*)(sp->blob + o_bq); sp->tab_bf = (float*)(sp->blob + o_bf);
+  bf16_t* sh_bf16 = (bf16_t*)(sp->blob + o_sh);
 
   int rc = JAT_OK;
   auto bail = [&](int code) { jat_sampler_destroy(sp); return code; };
@@ -599,6 +654,33 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
       return bail(fail(JAT_E_HIP, "memcpy ts"));
     if ((rc = time_path(m, wt, sp->ts_dev, steps, s)) != JAT_OK) return bail(rc);
     if ((rc = adaln_path(m, wt.t_silu, sp->mod_table, steps, 0, m->depth, s)) != JAT_OK) return bail(rc);
+    if (sp->folded) {
+      // fold tables: g = w_norm*(1+scale);  bq = shift_msa @ Wqkv^T;  bf = shift_mlp @ W1^T + b1   (per step, layer)
+      const int64_t mrow = (int64_t)m->depth * 6 * m->D;
+      for (int l = 0; l < m->depth; ++l) {
+        const LayerW& L = m->layers[l];
+        const float* mod_l = sp->mod_table + (int64_t)l * 6 * m->D;
+        if (launch_fold_scale(L.norm1, mod_l + 1 * m->D, mrow, sp->tab_g + ((int64_t)l * 2 + 0) * m->D,
+                              (int64_t)m->depth * 2 * m->D, steps, m->D, s) != hipSuccess ||
+            launch_fold_scale(L.norm2, mod_l + 4 * m->D, mrow, sp->tab_g + ((int64_t)l * 2 + 1) * m->D,
+                              (int64_t)m->depth * 2 * m->D, steps, m->D, s) != hipSuccess)
+          return bail(fail(JAT_E_HIP, "fold_scale launch"));
+        {
+          if (launch_gather_cast_rows(mod_l + 0 * m->D, mrow, sh_bf16, steps, m->D, s) != hipSuccess)
+            return bail(fail(JAT_E_HIP, "gather_cast launch"));
+          GemmArgs e{};
+          e.out = sp->tab_bq + (int64_t)l * Nqkv; e.ldo = (int64_t)m->depth * Nqkv; e.ntok = 1;
+          if ((rc = gemm(m, G_OTHER, sh_bf16, m->D, L.wqkv, m->D, steps, Nqkv, m->D, EPI_F32, e, s)) != JAT_OK) return bail(rc);
+        }
+        {
+          if (launch_gather_cast_rows(mod_l + 3 * m->D, mrow, sh_bf16, steps, m->D, s) != hipSuccess)
+            return bail(fail(JAT_E_HIP, "gather_cast launch"));
+          GemmArgs e{};
+          e.out = sp->tab_bf + (int64_t)l * m->mlp; e.ldo = (int64_t)m->depth * m->mlp; e.bias = L.b1; e.ntok = 1;
+          if ((rc = gemm(m, G_OTHER, sh_bf16, m->D, L.w1, m->D, steps, m->mlp, m->D, EPI_F32, e, s)) != JAT_OK) return bail(rc);
+        }
+      }
+    }
     if (hipStreamSynchronize(s) != hipSuccess) return bail(fail(JAT_E_HIP, "sync after table build"));
   }
   sp->w = carve(m, sp->Bf, ntok, (char*)sp->ws);

@@ -37,12 +37,26 @@ struct GemmArgs {
   // EPI_UNPATCH
   int C_out, T_orig;
   int dbg;  // profiling aid (bit0: suppress epilogue stores); 0 in production
+  // ---- norm folding (sampler path; coalesced-epilogue variants only) ------------------------------------------
+  // RMSNorm commutes with the matmul: norm(x)*g + sh  @ W^T  =  rstd[m] * ((x*g) @ W^T) + (sh @ W^T).
+  // producer (EPI_RESID / EPI_F32): besides x, emit A'[m][n] = bf16(x_new * fold_g[b][n]) and the row partial
+  //   sums of x_new^2 of this wave's column tile into fold_part[m][nw0 / wave_tile_n]  (plain stores, fixed order);
+  // consumer (any epilogue): scale the accumulator row m by rsqrt(sum_j rs_part[m][j] / K + 1e-6) before the bias.
+  bf16_t* fold_out;
+  const float* fold_g;
+  int64_t fold_g_bstride;
+  float* fold_part;
+  int fold_np;
+  const float* rs_part;
+  int rs_np;
 };
 
 // variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);
 int gemm_num_variants();
 void gemm_variant_tile(int variant, int* bm, int* bn);
+int gemm_variant_wave_n(int variant);   // columns per wave tile (fold_part slot width)
+bool gemm_variant_coalesced(int variant);
 
 // ---- attention -----------------------------------------------------------------------------------
 struct AttnArgs {
@@ -76,6 +90,10 @@ hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t
 // fp32 [rows, cols] -> bf16 with the rows of every 64-row head pair-interleaved for in-lane RoPE:
 // out row (h*64 + 2d + e) <- in row (h*64 + d + 32e), e in {0,1}   (rows % 64 == 0)
 hipError_t launch_cast_bf16_rope_rows(const float* in, bf16_t* out, int rows, int cols, hipStream_t s);
+// norm-folding table helpers: out[r][k] = w[k] * (1 + scale[r*in_stride + k]) ; out[r][k] = bf16(in[r*in_stride + k])
+hipError_t launch_fold_scale(const float* w, const float* scale, int64_t in_stride, float* out, int64_t out_stride,
+                             int rows, int cols, hipStream_t s);
+hipError_t launch_gather_cast_rows(const float* in, int64_t in_stride, bf16_t* out, int rows, int cols, hipStream_t s);
 // z += ((u + s(c-u)) - z)/(1-t+1e-5)*dt  (or z = x when t >= 0.999)  (infer_test_v3m2.py:161-179)
 hipError_t launch_cfg_euler(const float* xp, float* z, float cfg_scale, float t, float dt, int use_cfg,
                             int64_t n_per_half, hipStream_t s);
