@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cfg-scale", type=float, default=3.0)
     ap.add_argument("--config", default="v3mod2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long", action="store_true", help="skip the T=4096 chunked-inference leg (configs[4])")
     ap.add_argument("--eager", action="store_true", help="replay the sampler without the hipGraph (A/B)")
     args = ap.parse_args()
 
@@ -141,6 +142,27 @@ def main():
                              "latent_frames_per_s": B * T / (fwd_ms * 1e-3),
                              "tflops": fwd_flops_B / (fwd_ms * 1e-3) / 1e12,
                              "mfma_frac": fwd_flops_B / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+
+        # ---- long-sequence chunked inference (BASELINE configs[4]): one file of T=4096 latent frames -> 4 chunks
+        # (3 x 1378 + 478, overlap 172; infer_test_v3m2.py:340-404), equal-length chunks batched, 50-step CFG each
+        if not args.no_long:
+            T_long = 4096
+            lr_long = torch.from_numpy(recipe.gaussian("lr_long", (C_lat, T_long), 9)).to(dev)
+            mean = torch.zeros(C_lat, device=dev)
+            std = torch.ones(C_lat, device=dev)
+            plan = jatsr_amd.chunk_plan(T_long)
+            noise = [torch.from_numpy(recipe.gaussian("noise_long", (1, C_lat, b - a), i)).to(dev)
+                     for i, (a, b) in enumerate(plan)]
+            out_long = jatsr_amd.sample_long(model, lr_long, mean, std, mean, std, args.num_steps, args.cfg_scale, noise=noise)
+            torch.cuda.synchronize()
+            tl0 = time.perf_counter()
+            out_long = jatsr_amd.sample_long(model, lr_long, mean, std, mean, std, args.num_steps, args.cfg_scale, noise=noise)
+            torch.cuda.synchronize()
+            tl = time.perf_counter() - tl0
+            assert out_long.shape == (1, C_lat, T_long) and bool(torch.isfinite(out_long).all())
+            result["long_sequence"] = {"workload": f"T={T_long} frames in {len(plan)} chunks {[b - a for a, b in plan]}, "
+                                                   f"{args.num_steps}-step CFG={args.cfg_scale}, one GPU",
+                                       "ms": tl * 1e3, "latent_frames_per_s": T_long / tl}
 
         # ---- roofline of the dominant kernel (MLP fc1 GEMM: 28 launches per forward, 26 % of the FLOPs), measured
         # live: the same sampling run replayed eagerly with every fc1 launch bracketed by a HIP event pair on the

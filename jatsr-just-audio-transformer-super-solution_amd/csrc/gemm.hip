@@ -617,6 +617,118 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
     return;
   }
 
+  // ---- fused QKV projection + RoPE + GQA attention (ntok == 128): the 128 x 448 tile is ALL of q (5 heads), k, v
+  // of one (sample, KV group).  Accumulators -> RoPE -> bf16 operand images in LDS (Q [5][128][64], K [128][64],
+  // V^T [64][128], the layouts of attention.hip), then each of the 8 waves runs 16 query rows x 5 heads of
+  // softmax(QK^T/8)V straight from LDS.  q, k, v never touch HBM and the attention launch disappears.
+  if constexpr (EPI == EPI_QKV_ATTN) {
+    static_assert(BM == 128 && BN == 448 && NW == 8, "one block = one sample x one KV group");
+    constexpr int SQ = 0, SK = 5 * 16384, SV = SK + 16384;
+    static_assert(SV + 16384 <= 2 * STAGE, "operand images do not fit the staging buffers");
+    __builtin_amdgcn_s_barrier();
+    float2 invf[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int d0 = (((wn * TN * 16 + j * 16) & 63) >> 1) + fg * 2;
+      invf[j] = *(const float2*)(p.rope_inv_freq + d0);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wm * TM * 16 + i * 16 + frow;  // token position inside the sample (m0 = b * 128)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nl = wn * TN * 16 + j * 16;      // tile-local first column of this MFMA tile (wave-uniform)
+        const f32x4 v = acc[i][j] * rstd_rows[i];
+        if (nl < 384) {
+          const float r0 = __builtin_amdgcn_fractf((float)r * invf[j].x * 0.15915494309189535f);
+          const float r1 = __builtin_amdgcn_fractf((float)r * invf[j].y * 0.15915494309189535f);
+          const float c0 = __builtin_amdgcn_cosf(r0), c1 = __builtin_amdgcn_cosf(r1);
+          const float s0 = __builtin_amdgcn_sinf(r0), s1 = __builtin_amdgcn_sinf(r1);
+          const uint2 pk = pack4(v[0] * c0 - v[1] * s0, v[1] * c0 + v[0] * s0, v[2] * c1 - v[3] * s1, v[3] * c1 + v[2] * s1);
+          const int colb = ((nl & 63) + fg * 4) * 2, chunk = colb >> 4, off = colb & 15;
+          if (nl < 320) *(uint2*)(smem + SQ + (nl >> 6) * 16384 + r * 128 + ((chunk ^ (r & 7)) << 4) + off) = pk;
+          else *(uint2*)(smem + SK + r * 128 + ((chunk ^ ((r & 3) | (((r >> 3) & 1) << 2))) << 4) + off) = pk;
+        } else {
+          const int d0 = (nl - 384) + fg * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int d = d0 + e, kc = r >> 3;
+            *(unsigned short*)(smem + SV + d * 256 + (kc >> 3) * 128 + (((kc & 7) ^ (d & 7)) << 4) + (r & 7) * 2) = f2bf(v[e]);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int q = wave * 16 + frow;                // this lane's query row (B-operand column)
+    const int G = 5;
+    const int hbase = (n0 / 448) * G;
+    for (int h = 0; h < G; ++h) {
+      bf16x8 qf[2];
+      qf[0] = *(const bf16x8*)(smem + SQ + h * 16384 + q * 128 + (((0 + fg) ^ (q & 7)) << 4));
+      qf[1] = *(const bf16x8*)(smem + SQ + h * 16384 + q * 128 + (((4 + fg) ^ (q & 7)) << 4));
+      f32x4 st[8];
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const int r = 32 * (kt >> 1) + 8 * (frow >> 2) + (frow & 3) + 4 * (kt & 1);
+        const int ks = (r & 3) | (((r >> 3) & 1) << 2);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 kf = *(const bf16x8*)(smem + SK + r * 128 + (((s2 * 4 + fg) ^ ks) << 4));
+          st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s2], st[kt], 0, 0, 0);
+        }
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float nb = -mx * p.attn_scale_log2e;
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][e], p.attn_scale_log2e, nb));
+          st[kt][e] = pv;
+          sum += pv;
+        }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      bf16x8 pf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = (__bf16)st[2 * kk][e];
+          f[4 + e] = (__bf16)st[2 * kk + 1][e];
+        }
+        pf[kk] = f;
+      }
+      f32x4 o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int d = dt * 16 + frow, ch = kk * 4 + fg;
+          const bf16x8 vf = *(const bf16x8*)(smem + SV + d * 256 + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk], o[dt], 0, 0, 0);
+        }
+      if (m0 + q < p.M) {
+        bf16_t* op = (bf16_t*)p.out + (int64_t)(m0 + q) * p.ldo + (hbase + h) * 64 + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(uint2*)(op + dt * 16) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      }
+    }
+    return;
+  }
+
   // ---- direct epilogue: lane owns C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4) + reg -----------
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -737,6 +849,11 @@ static const int kVariantWaveN[] = {64, 64, 64, 64, 80, 80, 64, 64, 80, 112, 32,
 int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
 bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
+
+hipError_t launch_qkv_attn(const GemmArgs& a, hipStream_t s) {
+  if (a.ntok != 128 || a.N % 448 != 0 || a.M % 128 != 0) return hipErrorInvalidValue;
+  return launch_one<2, 4, 4, 7, 2, 0, EPI_QKV_ATTN>(a, s);
+}
 void gemm_variant_tile(int variant, int* bm, int* bn) {
   *bm = kVariantTile[variant][0];
   *bn = kVariantTile[variant][1];

@@ -42,6 +42,7 @@ static constexpr int HEAD_DIM = 64;
 
 struct LayerW {
   bf16_t *wqkv, *wo, *w1, *w2;  // [D+2kvD, D], [D, D], [mlp, D], [D, mlp]
+  bf16_t* wqkv_g = nullptr;     // group-major copy [Hkv][5*64 + 64 + 64][D] for the fused QKV+attention kernel (Hq/Hkv == 5)
   float *norm1, *norm2, *b1, *b2;
 };
 
@@ -159,9 +160,11 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
   const size_t o_pe_w1 = take((size_t)bott * m->Kp * 2), o_pe_w2 = take((size_t)D * bott * 2);
   const size_t o_wada = take((size_t)depth * 6 * D * D * 2), o_wfinal = take((size_t)m->Fout * D * 2);
   std::vector<size_t> o_qkv(depth), o_wo(depth), o_w1(depth), o_w2(depth), o_n1(depth), o_n2(depth), o_b1(depth),
-      o_b2(depth);
+      o_b2(depth), o_qkvg(depth);
+  const bool group5 = m->Hq / m->Hkv == 5;
   for (int l = 0; l < depth; ++l) {
     o_qkv[l] = take((size_t)(D + 2 * kvD) * D * 2); o_wo[l] = take((size_t)D * D * 2);
+    o_qkvg[l] = group5 ? take((size_t)(D + 2 * kvD) * D * 2) : 0;
     o_w1[l] = take((size_t)mlp * D * 2); o_w2[l] = take((size_t)D * mlp * 2);
     o_n1[l] = take((size_t)D * 4); o_n2[l] = take((size_t)D * 4);
     o_b1[l] = take((size_t)mlp * 4); o_b2[l] = take((size_t)D * 4);
@@ -187,6 +190,7 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
   for (int l = 0; l < depth; ++l) {
     LayerW& L = m->layers[l];
     L.wqkv = (bf16_t*)(base + o_qkv[l]); L.wo = (bf16_t*)(base + o_wo[l]);
+    L.wqkv_g = group5 ? (bf16_t*)(base + o_qkvg[l]) : nullptr;
     L.w1 = (bf16_t*)(base + o_w1[l]); L.w2 = (bf16_t*)(base + o_w2[l]);
     L.norm1 = (float*)(base + o_n1[l]); L.norm2 = (float*)(base + o_n2[l]);
     L.b1 = (float*)(base + o_b1[l]); L.b2 = (float*)(base + o_b2[l]);
@@ -242,6 +246,18 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
     to_bf16_rope(p + "attn.q_proj.weight", L.wqkv, D, D);
     to_bf16_rope(p + "attn.k_proj.weight", L.wqkv + (int64_t)D * D, kvD, D);
     to_bf16(p + "attn.v_proj.weight", L.wqkv + (int64_t)(D + kvD) * D, (int64_t)kvD * D);
+    if (group5 && rc == JAT_OK) {  // group-major copy: per KV head g: 5 q heads, its k head, its v head
+      const float* wq = find(p + "attn.q_proj.weight", (int64_t)D * D);
+      const float* wk = find(p + "attn.k_proj.weight", (int64_t)kvD * D);
+      const float* wv = find(p + "attn.v_proj.weight", (int64_t)kvD * D);
+      for (int g = 0; g < m->Hkv && wq && wk && wv; ++g) {
+        bf16_t* dst = L.wqkv_g + (int64_t)g * 448 * D;
+        if (launch_cast_bf16_rope_rows(wq + (int64_t)g * 320 * D, dst, 320, D, s) != hipSuccess ||
+            launch_cast_bf16_rope_rows(wk + (int64_t)g * 64 * D, dst + (int64_t)320 * D, 64, D, s) != hipSuccess ||
+            launch_cast_bf16(wv + (int64_t)g * 64 * D, dst + (int64_t)384 * D, (int64_t)64 * D, s) != hipSuccess)
+          rc = fail(JAT_E_HIP, "group-major qkv pack failed");
+      }
+    }
     to_bf16(p + "attn.out_proj.weight", L.wo, (int64_t)D * D);
     to_bf16(p + "mlp.0.weight", L.w1, (int64_t)mlp * D);
     to_f32(p + "mlp.0.bias", L.b1, mlp);
@@ -386,14 +402,26 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   const int D = m->D, M = B * ntok, Nqkv = D + 2 * m->kvD;
   const LayerW& L = m->layers[l];
   if (!f) KCHK(launch_norm_modulate(w.x, L.norm1, mod_l + 0 * D, mod_l + 1 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
-  {
+  const char* fuse_s = getenv("JAT_FUSE_QKV_ATTN");  // read per call so that tests can A/B the two paths in one process
+  const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
+  // one block per (sample, KV group): worth it only when B * Hkv blocks fill the 256 CUs (measured: +1.8 % at
+  // B = 56, -5 % at B = 28); fuse_env = 2 forces it (tests)
+  const bool fused_attn = fuse_env && L.wqkv_g && ntok == 128 && !f && (B * m->Hkv >= 192 || fuse_env == 2);
+  if (fused_attn) {
+    // q/k/v projection + RoPE + attention of one (sample, KV group) per block: q, k, v stay in LDS
+    GemmArgs a{};
+    a.A = w.xn; a.lda = D; a.W = L.wqkv_g; a.ldw = D; a.M = M; a.N = m->Hkv * 448; a.K = D;
+    a.out = w.ao; a.ldo = D; a.ntok = ntok; a.rope_inv_freq = m->rope_invf;
+    a.attn_scale_log2e = 0.125f * 1.4426950408889634f;
+    KCHK(launch_qkv_attn(a, s));
+  } else {
     GemmArgs e{};
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = ntok;
     e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin; e.rope_inv_freq = m->rope_invf;
     if (f) { e.rs_part = w.part; e.bias = f->bq + (int64_t)l * Nqkv; }
     JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, Nqkv, D, EPI_QKV_ROPE, e, s));
   }
-  {
+  if (!fused_attn) {
     AttnArgs a{};
     a.q = w.q; a.k = w.k; a.vt = w.vt; a.o = w.ao; a.ldq = D; a.ldk = m->kvD; a.ldo = D;
     a.B = B; a.N = ntok; a.Hq = m->Hq; a.Hkv = m->Hkv; a.npad = w.npad;

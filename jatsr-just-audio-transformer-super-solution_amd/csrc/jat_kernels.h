@@ -12,6 +12,7 @@ enum GemmEpi : int {
   EPI_BF16_GELU = 2, // out bf16 = gelu_erf(acc + bias)        (jat_audiosr_v3.py:221-225, 266-268)
   EPI_RESID = 3,     // out fp32 [M,ldo] += gate[b,n]*(acc+bias) (jat_audiosr_v3.py:300,306)
   EPI_QKV_ROPE = 4,  // RoPE on q,k heads; q->[M,D], k->[M,kvD], v->vt[B,Hkv,64,Npad] (:154-160)
+  EPI_QKV_ATTN = 6,  // fused: QKV projection + RoPE + GQA attention of one (sample, KV group) per block; out = attn_out
   EPI_UNPATCH = 5,   // out fp32 [B,C,T_orig]: feature c*4+p of token n -> [b,c,4n+p] (:406-420,465-469)
 };
 
@@ -49,11 +50,15 @@ struct GemmArgs {
   int fold_np;
   const float* rs_part;
   int rs_np;
+  float attn_scale_log2e;  // EPI_QKV_ATTN: (1/sqrt(64)) * log2(e)
 };
 
 // variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);
 int gemm_num_variants();
+// Fused QKV projection + RoPE + attention for ntok == 128 (W = group-major fused weight [Hkv][5*64+64+64][K]):
+// one block per (sample, KV group); a.out = attention output bf16 [M, D]; a.N = Hkv * 448.
+hipError_t launch_qkv_attn(const GemmArgs& a, hipStream_t s);
 void gemm_variant_tile(int variant, int* bm, int* bn);
 int gemm_variant_wave_n(int variant);   // columns per wave tile (fold_part slot width)
 bool gemm_variant_coalesced(int variant);

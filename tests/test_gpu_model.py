@@ -75,6 +75,21 @@ def test_forward_vs_oracle_micro_batch_rows_independent():
     assert rel_l2(full, ref) < FWD_TOL
 
 
+def test_fused_qkv_attention_is_bit_identical_to_separate_kernels(monkeypatch):
+    """At N = 128 tokens the q/k/v projection + RoPE + attention run as ONE kernel per (sample, KV group) with q, k, v
+    kept in LDS.  The K-accumulation order and the softmax arithmetic are the same as in the separate QKV GEMM +
+    attention kernels, so the two paths must agree bit for bit."""
+    z, meta = load_golden("fwd_v3mod2_T512")
+    cfg, x_t, t, x_c = fwd_inputs(meta)
+    m = build(meta["cfg"], meta["norm"], meta["salt"])
+    monkeypatch.setenv("JAT_FUSE_QKV_ATTN", "2")    # 2 = force (the default only fuses when B*Hkv fills the GPU)
+    fused = m(cuda(x_t), cuda(t), cuda(x_c))
+    monkeypatch.setenv("JAT_FUSE_QKV_ATTN", "0")
+    separate = m(cuda(x_t), cuda(t), cuda(x_c))
+    assert torch.equal(fused, separate)
+    assert rel_l2(sub(fused.cpu().numpy(), *meta["s_out"]), z["out64"]) < FWD_TOL
+
+
 def test_time_embed_vs_oracle():
     cfg = recipe.CONFIGS["micro"]
     m = build("micro")
