@@ -178,10 +178,18 @@ def main():
         g_ms = tot_ms.value / max(n_l.value, 1)
         g_flops = fl.value / max(n_l.value, 1)
         ach = g_flops / (g_ms * 1e-3) / 1e12
+        traffic = None   # L2-miss bytes per launch from the committed PMC passes (same kernel, same shape), if any
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+            traffic = pmc.get(f"fc1_variant{var.value}_M{Mg}_N{Ng}_K{Kg}", {}).get("traffic_bytes")
+        except Exception:
+            pass
         result["roofline"] = {"kernel": f"gemm_bf16_kernel<...,EPI_BF16_GELU> tile variant {var.value} (MLP fc1) "
                                         f"M={Mg} N={Ng} K={Kg}",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                              "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                              "traffic_note": "bytes/launch = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01/pmc_traffic.json "
+                                              "(separate --pmc passes; fabric-side, Infinity-Cache hits included)",
                               "flops_per_launch": g_flops, "avg_launch_ms": g_ms, "launches_timed": n_l.value}
 
         # ---- CPU baseline: numpy oracle (port of the reference fp32 CPU forward) on a bounded sample --------
