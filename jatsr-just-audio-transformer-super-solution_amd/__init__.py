@@ -14,6 +14,7 @@ _LAZY = {
     "GroupedQueryAttention": "model", "load_model": "model",
     "flow_matching_sample": "sampler", "crossfade_chunks": "sampler", "chunk_plan": "sampler",
     "sample_long": "sampler", "Sampler": "sampler", "channel_affine": "sampler",
+    "load_latent_file": "io", "save_latent_file": "io", "load_stats": "io",
 }
 __all__ = ["recipe"] + sorted(_LAZY)
 
