@@ -103,7 +103,7 @@ __device__ __forceinline__ void fold_emit(const GemmArgs& p, char* slot, float4 
 // register allocation accordingly (2nd launch-bounds argument = waves per SIMD).
 // PIPE 6 adds 4 DMA-only waves (one per SIMD) to the 8 MFMA waves: 768 threads, three waves per SIMD.
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
-__global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
+__global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
     gemm_bf16_kernel(const GemmArgs p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 64;
   constexpr int NW = WM * WN;
@@ -361,6 +361,70 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       cur = cur == 2 ? 0 : cur + 1;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else if constexpr (PIPE == 7) {
+    // 8 MFMA waves + 4 DMA waves as PIPE 6, but WITHOUT ping-pong slots: the MFMA waves run the mid-tile-barrier loop
+    // of PIPE 2 (fragments one k-step ahead in registers) and never issue DMA; ONE barrier per K-tile for all 12 waves.
+    static_assert(NW == 8 && PA % 4 == 0 && PB % 4 == 0, "PIPE 7: 8 MFMA waves + 4 DMA waves");
+    constexpr int NDW = 4, AI6 = PA / NDW, BI6 = PB / NDW;
+    if (wave >= NW) {
+      const int dw = wave - NW;
+      const bf16_t* asrc[AI6];
+      const bf16_t* bsrc[BI6];
+#pragma unroll
+      for (int j = 0; j < AI6; ++j)
+        asrc[j] = p.A + (int64_t)min(m0 + (dw + j * NDW) * 8 + srow, p.M - 1) * p.lda + schunk * 8;
+#pragma unroll
+      for (int j = 0; j < BI6; ++j) bsrc[j] = p.W + (int64_t)(n0 + (dw + j * NDW) * 8 + srow) * p.ldw + schunk * 8;
+      auto issue = [&](int st, int kt) {
+#pragma unroll
+        for (int j = 0; j < AI6; ++j)
+          __builtin_amdgcn_global_load_lds((const void*)(asrc[j] + kt * BK),
+                                           (lds_ptr_t)(smem + st * STAGE + (dw + j * NDW) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BI6; ++j)
+          __builtin_amdgcn_global_load_lds((const void*)(bsrc[j] + kt * BK),
+                                           (lds_ptr_t)(smem + st * STAGE + A_BYTES + (dw + j * NDW) * 1024), 16, 0, 0);
+      };
+      issue(0, 0);
+      if (nk > 1) {
+        issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI6 + BI6) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // tile 0 visible
+      int st = 2;
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) {
+          issue(st, kt + 2);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI6 + BI6) : "memory");  // tile kt+1 landed, tile kt+2 in flight
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        st = st == 2 ? 0 : st + 1;
+      }
+      if constexpr (CE && EPI <= EPI_QKV_ROPE) __builtin_amdgcn_s_barrier();
+      return;
+    }
+    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
+    __builtin_amdgcn_s_barrier();
+    read_frags(a0, w0, 0, coff0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nxt = cur == 2 ? 0 : cur + 1;
+      read_frags(a1, w1, cur, coff1);
+      __builtin_amdgcn_s_setprio(1);
+      mma(a0, w0);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();       // tile kt+1 landed (DMA waves waited for it); stage of tile kt-1 is free
+      read_frags(a0, w0, nxt, coff0);     // harmless when kt+1 == nk
+      __builtin_amdgcn_s_setprio(1);
+      mma(a1, w1);
+      __builtin_amdgcn_s_setprio(0);
+      cur = nxt;
+    }
   } else if constexpr (PIPE == 5) {
     // Ping-pong as PIPE 4, but the W pieces of tile kt+2 are issued from inside the MFMA slot (between the two
     // k-steps), so the load slot (fragment reads + A pieces) is no longer the longer of the two slots.
@@ -814,7 +878,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   if (a.N % BN != 0 || a.K % 64 != 0 || a.M <= 0) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3((WM * WN + (PIPE == 6 ? 4 : 0)) * 64), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64), LDS, s, a);
   return hipGetLastError();
 }
 
@@ -843,9 +907,10 @@ static const int kVariantTile[][2] = {
     {256, 160},                                      // 24: PIPE 5 (ping-pong, W pieces issued in the MFMA slot)
     {256, 160}, {256, 128},                          // 25-26: PIPE 6 (8 MFMA waves + 4 DMA waves)
     {64, 160}, {64, 128},                            // 27-28: small-M tiles (PIPE 2 + coalesced epilogue)
+    {256, 160}, {256, 128},                          // 29-30: PIPE 7 (8 MFMA + 4 DMA waves, one barrier per K-tile)
 };
 static const int kVariantWaveN[] = {64, 64, 64, 64, 80, 80, 64, 64, 80, 112, 32, 64, 80, 80, 80, 64, 80, 32,
-                                    80, 80, 64, 64, 80, 64, 80, 80, 64, 80, 64};
+                                    80, 80, 64, 64, 80, 64, 80, 80, 64, 80, 64, 80, 64};
 int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
 bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
@@ -892,6 +957,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 26: return launch_epi<4, 2, 4, 4, 6, 1>(a, epi, s);
     case 27: return launch_epi<2, 2, 2, 5, 2, 1>(a, epi, s);
     case 28: return launch_epi<2, 2, 2, 4, 2, 1>(a, epi, s);
+    case 29: return launch_epi<4, 2, 4, 5, 7, 1>(a, epi, s);
+    case 30: return launch_epi<4, 2, 4, 4, 7, 1>(a, epi, s);
   }
   return hipErrorInvalidValue;
 }

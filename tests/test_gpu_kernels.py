@@ -84,7 +84,7 @@ GEMM_SHAPES = [(128, 128, 64), (256, 512, 128), (1000, 1792, 1280), (56, 1536, 2
                (384, 256, 8192)]
 
 
-@pytest.mark.parametrize("variant", list(range(29)))
+@pytest.mark.parametrize("variant", list(range(31)))
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm(variant, M, N, K, epi):
