@@ -47,3 +47,23 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def sample_long_sharded(sample_chunks_fn, plan, group=None):
+    """BASELINE configs[4] layout: the chunks of one long file (reference chunk plan, infer_test_v3m2.py:340-361)
+    are independent, so rank r samples chunks r, r + world, ... with `sample_chunks_fn(indices) -> {index: tensor}`
+    and every rank receives all generated chunks in plan order (ready for `crossfade_chunks`).  Chunk lengths
+    differ (the last one is shorter), so the exchange is an object gather of CPU tensors — it happens once per
+    file, outside the sampling loop, which has no collective."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = list(range(rank, len(plan), world))
+    local = {i: t.detach().cpu() for i, t in sample_chunks_fn(mine).items()} if mine else {}
+    if world == 1:
+        return [local[i] for i in range(len(plan))]
+    parts = [None] * world
+    dist.all_gather_object(parts, local, group=group)
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    return [merged[i] for i in range(len(plan))]

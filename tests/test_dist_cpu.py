@@ -29,8 +29,20 @@ def _worker(rank, world, port, q):
 
     full = sample_sharded(fn, lr, z0)
     t = max_over_ranks(1.0 + rank)
+    # config-5 layout: chunks of one long file sharded over ranks, gathered in plan order, crossfaded
+    from jatsr_amd.dist import sample_long_sharded
+    plan = O.chunk_plan(100, 40, 8)
+    lr_long = recipe.gaussian("long_lr", (1, 32, 100), 5)
+    noise = [recipe.gaussian("noise", (1, 32, b - a), i) for i, (a, b) in enumerate(plan)]
+
+    def chunk_fn(idx):
+        return {i: torch.from_numpy(O.flow_matching_sample(orc, lr_long[:, :, plan[i][0]:plan[i][1]], noise[i], 2, 2.0))
+                for i in idx}
+
+    chunks = sample_long_sharded(chunk_fn, plan)
+    long_out = O.crossfade_chunks([c.numpy() for c in chunks], 8)
     if rank == 0:
-        q.put((full.numpy(), t))
+        q.put((full.numpy(), t, long_out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,7 +56,7 @@ def test_sharded_sampling_equals_unsharded_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, tmax = q.get(timeout=300)
+    got, tmax, long_out = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -55,3 +67,9 @@ def test_sharded_sampling_equals_unsharded_gloo_world2():
     ref = O.flow_matching_sample(orc, lr, z0, 3, 2.0)
     assert got.shape == ref.shape and np.allclose(got, ref, atol=1e-5)
     assert tmax == 2.0
+    plan = O.chunk_plan(100, 40, 8)
+    lr_long = recipe.gaussian("long_lr", (1, 32, 100), 5)
+    noise = [recipe.gaussian("noise", (1, 32, b - a), i) for i, (a, b) in enumerate(plan)]
+    ref_long = O.crossfade_chunks([O.flow_matching_sample(orc, lr_long[:, :, a:b], noise[i], 2, 2.0)
+                                   for i, (a, b) in enumerate(plan)], 8)
+    assert long_out.shape == (1, 32, 100) and np.allclose(long_out, ref_long, atol=1e-5)
