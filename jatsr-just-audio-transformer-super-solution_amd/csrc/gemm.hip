@@ -524,6 +524,8 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
     for (int j = 0; j < TN; ++j)
       bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] const bool fold = OUT32 && p.fold_out != nullptr;
+    const int npass = (EPI == EPI_BF16_GELU && p.dual_rows > 0) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass)
 #pragma unroll
     for (int ig = 0; ig < TM / 2; ++ig) {
 #pragma unroll
@@ -532,6 +534,13 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
         for (int j = 0; j < TN; ++j) {
           f32x4 v = acc[2 * ig + ii][j] * rstd_rows[2 * ig + ii];
           v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w;
+          if constexpr (EPI == EPI_BF16_GELU) {
+            if (npass == 2 && pass == 0) {
+              const int mrow = min(mw0 + (2 * ig + ii) * 16 + frow, p.M - 1);
+              const float4 da = *(const float4*)(p.dual_add + (int64_t)mrow * p.N + nw0 + j * 16 + fg * 4);
+              v[0] += da.x; v[1] += da.y; v[2] += da.z; v[3] += da.w;
+            }
+          }
           char* dst = wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * EB;
           if constexpr (OUT32) {
             *(float4*)dst = float4{v[0], v[1], v[2], v[3]};
@@ -564,7 +573,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
                         float4{__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)},
                         m, n, m / p.ntok);
           } else {
-            *(uint4*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = raw;
+            *(uint4*)((bf16_t*)p.out + (int64_t)(m + pass * p.dual_rows) * p.ldo + n) = raw;
           }
         } else if (OUT32 && fold) {
           *(float*)(wbuf + row * RS + cc * 16) = 0.f;

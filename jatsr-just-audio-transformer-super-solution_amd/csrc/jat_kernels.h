@@ -51,6 +51,10 @@ struct GemmArgs {
   const float* rs_part;
   int rs_np;
   float attn_scale_log2e;  // EPI_QKV_ATTN: (1/sqrt(64)) * log2(e)
+  // EPI_BF16_GELU dual output (sampler patch embed): rows m get gelu(acc + bias + dual_add[m][n]), rows m + dual_rows
+  // get gelu(acc + bias): the CFG cond / uncond halves share the z contribution of the first patch-embed Linear.
+  const float* dual_add;
+  int dual_rows;
 };
 
 // variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)
