@@ -346,19 +346,43 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
     int cur = 0;
+    // optional timeline (diagnostic build path, taken only when dbg_out is set): cycles per slot phase
+    unsigned long long tl_load = 0, tl_b1 = 0, tl_mma = 0, tl_b2 = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    const bool tl = p.dbg_out != nullptr;
+#define JAT_STAMP(x)                                                                  \
+  if (tl) {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  }
+    JAT_STAMP(ts0)
     for (int kt = 0; kt < nk; ++kt) {
       read_frags(a0, w0, cur, coff0);
       read_frags(a1, w1, cur, coff1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      JAT_STAMP(ts1)
       __builtin_amdgcn_s_barrier();
+      JAT_STAMP(ts2)
       __builtin_amdgcn_s_setprio(1);
       mma(a0, w0);
       mma(a1, w1);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      JAT_STAMP(ts3)
       __builtin_amdgcn_s_barrier();
+      if (tl) {
+        unsigned long long ts4;
+        JAT_STAMP(ts4)
+        tl_load += ts1 - ts0; tl_b1 += ts2 - ts1; tl_mma += ts3 - ts2; tl_b2 += ts4 - ts3;
+        ts0 = ts4;
+      }
       cur = cur == 2 ? 0 : cur + 1;
+    }
+#undef JAT_STAMP
+    if (tl && lane == 0) {
+      unsigned long long* o = p.dbg_out + ((size_t)blockIdx.x * NW + wave) * 4;
+      o[0] = tl_load; o[1] = tl_b1; o[2] = tl_mma; o[3] = tl_b2;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
   } else if constexpr (PIPE == 7) {
@@ -551,20 +575,36 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
           }
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // EPI_RESID: issue ALL residual / gate loads of the group first.  Written chunk by chunk, the store of chunk t
+      // and the load of chunk t+1 hit the same buffer, the compiler cannot prove them disjoint and serialises
+      // 10 global round trips per group (measured: ~13 us of a 34 us out_proj launch).
+      constexpr int NHALF = (EPI == EPI_RESID) ? 2 : 1, HCH = NCH / NHALF;   // two batches: 40 VGPRs of loads in flight
+      static_assert(NCH % NHALF == 0, "chunk count must split evenly");
 #pragma unroll
-      for (int t = 0; t < NCH; ++t) {
+      for (int hh = 0; hh < NHALF; ++hh) {
+      [[maybe_unused]] f32x4 xs[HCH], gs[HCH];
+      if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int tt = 0; tt < HCH; ++tt) {
+          const int c = lane + 64 * (hh * HCH + tt), row = c / CPR, cc = c - row * CPR;
+          const int m = min(mw0 + ig * 32 + row, p.M - 1), n = nw0 + cc * EPC;
+          xs[tt] = *(const f32x4*)((const float*)p.out + (int64_t)m * p.ldo + n);
+          gs[tt] = *(const f32x4*)(p.gate + (int64_t)(m / p.ntok) * p.gate_bstride + n);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < HCH; ++tt) {
+        const int t = hh * HCH + tt;
         const int c = lane + 64 * t, row = c / CPR, cc = c - row * CPR;
         const int m = mw0 + ig * 32 + row, n = nw0 + cc * EPC;
         const uint4 raw = *(const uint4*)(wbuf + row * RS + cc * 16);
         if (m < p.M) {
           if constexpr (EPI == EPI_RESID) {
             const int b = m / p.ntok;
-            const float4 g = *(const float4*)(p.gate + (int64_t)b * p.gate_bstride + n);
-            float4* xp = (float4*)((float*)p.out + (int64_t)m * p.ldo + n);
-            float4 x = *xp;
-            x.x += g.x * __uint_as_float(raw.x); x.y += g.y * __uint_as_float(raw.y);
-            x.z += g.z * __uint_as_float(raw.z); x.w += g.w * __uint_as_float(raw.w);
-            *xp = x;
+            float4 x;
+            x.x = xs[tt][0] + gs[tt][0] * __uint_as_float(raw.x); x.y = xs[tt][1] + gs[tt][1] * __uint_as_float(raw.y);
+            x.z = xs[tt][2] + gs[tt][2] * __uint_as_float(raw.z); x.w = xs[tt][3] + gs[tt][3] * __uint_as_float(raw.w);
+            *(float4*)((float*)p.out + (int64_t)m * p.ldo + n) = x;
             if (fold) fold_emit(p, wbuf + row * RS + cc * 16, x, m, n, b);
           } else if constexpr (EPI == EPI_F32) {
             *(uint4*)((float*)p.out + (int64_t)m * p.ldo + n) = raw;
@@ -578,6 +618,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
         } else if (OUT32 && fold) {
           *(float*)(wbuf + row * RS + cc * 16) = 0.f;
         }
+      }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr (OUT32) {

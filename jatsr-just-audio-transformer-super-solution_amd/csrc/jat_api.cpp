@@ -818,6 +818,7 @@ extern "C" int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bia
   a.out = C; a.ldo = N; a.bias = bias; a.gate = gate; a.gate_bstride = gate_bstride;
   a.ntok = rows_per_batch > 0 ? rows_per_batch : 1;
   if (const char* d = getenv("JAT_GEMM_DBG")) a.dbg = atoi(d);
+  if (const char* d = getenv("JAT_GEMM_TIMELINE")) a.dbg_out = (unsigned long long*)strtoull(d, nullptr, 0);  // tools/gemm_timeline.py
   KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
   return JAT_OK;
 }

@@ -55,6 +55,7 @@ struct GemmArgs {
   // get gelu(acc + bias): the CFG cond / uncond halves share the z contribution of the first patch-embed Linear.
   const float* dual_add;
   int dual_rows;
+  unsigned long long* dbg_out;  // profiling aid (tools/gemm_timeline.py): per-wave cycle sums of the PIPE 6 slot phases
 };
 
 // variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)
