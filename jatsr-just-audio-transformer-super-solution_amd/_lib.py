@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libjat_hip.so")
+LIB_PATH = os.environ.get("JAT_LIB_PATH") or os.path.join(_HERE, "csrc", "libjat_hip.so")   # override: A/B two builds
 
 JAT_OK, JAT_E_INVALID, JAT_E_HIP, JAT_E_STATE, JAT_E_SEQLEN = 0, -1, -2, -3, -4
 NORM_RMS_W, NORM_LN_NOAFFINE = 0, 1
