@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/train_*.npz: one optimisation step of the REFERENCE model under torch autograd.
+
+Build container only (needs /root/reference and CPU PyTorch):
+
+    python oracle/gen_golden_train.py            # all cases
+    python oracle/gen_golden_train.py micro      # a subset
+
+What is pinned (training row a14 of SURVEY.md §8; the step body lives inline in `main()` of
+train_ddp_v3m2.py:533-622, which cannot be imported — it needs tensorboard and a process group — so the few tensor
+statements of the step are issued here against the reference's own model class, `torch.nn.functional.mse_loss`,
+`torch.nn.utils.clip_grad_norm_` and `torch.optim.AdamW`, i.e. the very functions the trainer calls):
+
+    z_t   = t * hr_norm + (1 - t) * noise                    train_ddp_v3m2.py:577-579
+    lr_in = lr_norm * (~cfg_mask)                            :568-571
+    pred  = model(z_t, t, lr_in)                             :582     (train mode, dropout = drop_path = 0)
+    loss  = mse_loss(pred, hr_norm)                          :585
+    loss.backward(); clip_grad_norm_(params, 1.0)            :610-615
+    AdamW(lr, weight_decay=0.1).step()                       :423,618
+
+`u_shaped_timestep_sampling` (:164-172) is a top-level function and is taken from the file itself with `ast`.
+Stochastic regularisers (Dropout / DropPath, torch's Philox streams) are outside what a fixture can pin; the cases
+run with both rates 0.  Only inputs-by-recipe metadata and expected VALUES are written (subsampled for the large
+matrices, plus their full L2 norms).
+"""
+from __future__ import annotations
+
+import ast
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import jatsr_amd.recipe as recipe  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+FULL_LIMIT = 4096          # tensors up to this many elements are stored whole
+
+
+def ref_model(cfg, norm, salt, dtype):
+    with contextlib.redirect_stdout(io.StringIO()):
+        if norm == "rms":
+            from src.models.jat_audiosr_v3 import JaT_AudioSR_V3 as Cls
+        else:
+            from src.models.jat_audiosr_v2 import JaT_AudioSR_V2 as Cls
+        m = Cls(**cfg, dropout=0.0, drop_path_rate=0.0)
+    sd = {k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg, norm, salt).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(".rope." in k for k in missing)
+    return m.to(dtype).train()
+
+
+def sub(a, strides):
+    """Values are stored as fp32 (of the fp64 run): the HIP path's own error is 1e-3..1e-2."""
+    a = np.asarray(a, dtype=np.float32)
+    if a.size <= FULL_LIMIT or a.ndim != 2:
+        return np.ascontiguousarray(a if a.size <= FULL_LIMIT else a.reshape(-1)[::strides[0] * strides[1]])
+    return np.ascontiguousarray(a[::strides[0], ::strides[1]])
+
+
+def step_inputs(cfg, B, T, salt):
+    C = cfg["input_channels"]
+    hr = recipe.gaussian("train_hr", (B, C, T), salt + 300)
+    lr = recipe.gaussian("train_lr", (B, C, T), salt + 301)
+    noise = recipe.gaussian("train_noise", (B, C, T), salt + 302)
+    return hr, lr, noise
+
+
+def train_case(name, cfg_name, B, T, t_list, mask_list, norm="rms", salt=0, lr_rate=5e-5, wd=0.1, clip=1.0,
+               strides=(7, 5)):
+    cfg = recipe.CONFIGS[cfg_name]
+    hr, lr, noise = step_inputs(cfg, B, T, salt)
+    t = np.asarray(t_list, dtype=np.float32)
+    mask = np.asarray(mask_list, dtype=bool)
+    rec = {}
+    for tag, dt in (("64", torch.float64), ("32", torch.float32)):
+        m = ref_model(cfg, norm, salt, dt)
+        hr_t, lr_t, nz = (torch.from_numpy(a).to(dt) for a in (hr, lr, noise))
+        tt = torch.from_numpy(t).to(dt)
+        cfg_mask = torch.from_numpy(mask).view(B, 1, 1)
+        lr_in = lr_t * (~cfg_mask).to(dt)
+        tv = tt.view(-1, 1, 1)
+        z_t = tv * hr_t + (1 - tv) * nz
+        opt = torch.optim.AdamW(m.parameters(), lr=lr_rate, weight_decay=wd)
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        pred = m(z_t, tt, lr_in)
+        loss = torch.nn.functional.mse_loss(pred, hr_t)
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        gnorm = torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+        opt.step()
+        rec[f"loss{tag}"] = np.float64(loss.item())
+        rec[f"gnorm{tag}"] = np.float64(gnorm.item())
+        if tag == "64":
+            rec["pred_l2"] = np.float64(pred.detach().norm().item())
+            for k, g in grads.items():
+                rec["g_" + k] = sub(g.numpy(), strides)
+                rec["gl2_" + k] = np.float64(g.norm().item())
+                d = (dict(m.named_parameters())[k].detach() - before[k]).numpy()
+                rec["d_" + k] = sub(d, strides)
+                rec["dl2_" + k] = np.float64(np.linalg.norm(d))
+        else:
+            g64 = rec  # fp32-vs-fp64 noise floor of the reference itself, per tensor (max over tensors reported)
+            worst = 0.0
+            for k, g in grads.items():
+                ref = g64["gl2_" + k]
+                if ref > 0:
+                    worst = max(worst, abs(float(g.double().norm()) - ref) / ref)
+            rec["g32_norm_dev_max"] = np.float64(worst)
+    rec["meta"] = json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, t=[float(v) for v in t],
+                                  mask=[bool(v) for v in mask], norm=norm, salt=salt, lr=lr_rate, wd=wd, clip=clip,
+                                  full_limit=FULL_LIMIT, strides=strides, torch=torch.__version__,
+                                  names=[k for k, _ in ref_model(cfg, norm, salt, torch.float32).named_parameters()]))
+    np.savez_compressed(os.path.join(GOLD, f"train_{name}.npz"), **rec)
+    sz = os.path.getsize(os.path.join(GOLD, f"train_{name}.npz"))
+    print(f"[golden] train_{name}: loss={rec['loss64']:.6f} gnorm={rec['gnorm64']:.4f} "
+          f"loss32-loss64={rec['loss32'] - rec['loss64']:.2e} ({sz / 1024:.0f} KiB)")
+
+
+def u_shape_case():
+    src = open(os.path.join(REF, "train_ddp_v3m2.py"), encoding="utf-8").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "u_shaped_timestep_sampling"]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "train_ddp_v3m2.py", "exec"), ns)
+    u = recipe.uniform("u_shape", (64,), 5).astype(np.float32) * 0.5 + 0.5   # recipe.uniform is in [-1, 1)
+    u[:4] = [0.0, 0.5, 0.25, 0.999999]
+    real = torch.rand
+    torch.rand = lambda *a, **k: torch.from_numpy(u).clone()
+    try:
+        t = ns["u_shaped_timestep_sampling"](64, "cpu").numpy()
+    finally:
+        torch.rand = real
+    np.savez_compressed(os.path.join(GOLD, "train_misc.npz"), u=u, t_ushape=t)
+    print(f"[golden] train_misc: t in [{t.min():.4f}, {t.max():.4f}]")
+
+
+def main(which):
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 8)
+    allc = not which
+    if allc or "micro" in which:
+        train_case("micro_T24", "micro", 2, 24, [0.1, 0.85], [False, True])
+        train_case("micro_T22_pad", "micro", 3, 22, [0.02, 0.5, 0.97], [False, False, True], salt=1)
+        train_case("micro_ln_T24", "micro", 2, 24, [0.3, 0.6], [False, False], norm="ln", salt=2)
+    if allc or "tiny" in which:
+        train_case("tiny_T128", "tiny", 2, 128, [0.2, 0.9], [False, True], strides=(61, 53))
+        train_case("tiny_T1378", "tiny", 1, 1378, [0.4], [False], salt=1, strides=(61, 53))
+    if allc or "misc" in which:
+        u_shape_case()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
