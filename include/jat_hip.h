@@ -112,6 +112,37 @@ int jat_channel_affine(const float* in, const float* mean, const float* std, flo
 int jat_crossfade_pair(const float* prev, int32_t Tp, const float* cur, int32_t Tc, int32_t overlap,
                        float* out, int32_t rows, void* stream);
 
+/* ---- training step (train_ddp_v3m2.py:533-622) ------------------------------------ */
+/* The step is split at its only cross-device boundary, the DDP gradient all-reduce (train_ddp_v3m2.py:486,610):
+ *   jat_trainer_prepare   z_t = t x + (1-t) eps, cond noise, CFG condition dropout            (:548-579)
+ *   jat_trainer_fwd_bwd   pred = model(z_t, t, cond); loss = mse_loss(pred, target); backward  (:582-610)
+ *   [caller: all-reduce(grads_flat) / world_size over RCCL when world_size > 1]
+ *   jat_trainer_optim     unscale, clip_grad_norm_(max_norm), AdamW, re-pack bf16 operands     (:613-619)
+ * Parameters, gradients and the two AdamW moments are four caller-owned flat fp32 device buffers of `total` floats
+ * (total % 4 == 0); `params` names the reference state_dict tensors as 16-byte aligned slices of params_flat, and the
+ * gradient / moment of a tensor lives at the same offset of its buffer.  Gaps between tensors must be zero-filled.
+ * Dropout / DropPath (jat_audiosr_v3.py:38-64,139,269-271) are not implemented: the step is the reference's with
+ * dropout = drop_path_rate = 0.  Per-rank batch B <= 32. */
+typedef struct jat_trainer jat_trainer;
+int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, int32_t n_params, float* params_flat,
+                       float* grads_flat, float* exp_avg, float* exp_avg_sq, int64_t total, int32_t B, int32_t T,
+                       void* stream, jat_trainer** out);
+void jat_trainer_destroy(jat_trainer* tr);
+int jat_trainer_workspace_bytes(const jat_trainer* tr, size_t* out);
+/* hr_norm, noise, z_t: [B,C,T]; cond [B,Cc,T] is modified in place: cond = (cond + cond_noise * ratio *
+ * (adaptive ? clamp(std(cond), 0.5, 2) : 1)) * keep[b]   (cond_noise / keep may be NULL); t [B]. */
+int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float* cond, const float* noise,
+                        const float* cond_noise, float cond_noise_ratio, int32_t adaptive, const float* keep,
+                        const float* t, float* z_t, void* stream);
+/* Overwrites grads_flat with d(loss * loss_scale)/d(param); loss_out (device, 1 float, nullable) = unscaled loss;
+ * x_pred_out (device [B,C,T], nullable) = the prediction. */
+int jat_trainer_fwd_bwd(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond, const float* target,
+                        float loss_scale, float* loss_out, float* x_pred_out, void* stream);
+/* grad_norm_out (device, 1 float, nullable) = L2 norm of the loss-SCALED gradients (divide by loss_scale).  A
+ * non-finite norm leaves parameters and moments untouched (GradScaler.step).  `step` is 1-based (bias correction). */
+int jat_trainer_optim(jat_trainer* tr, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float max_grad_norm, float loss_scale, int32_t step, float* grad_norm_out, void* stream);
+
 /* ---- per-kernel entry points (unit parity tests; bench roofline leg) --------------------------------- */
 /* y_bf16[M,D] = norm(x[M,D]) (* w) * (1 + scale[b]) + shift[b], b = row / rows_per_batch;
  * shift/scale may be NULL (no modulation); mod_bstride = element stride between batches (0 = shared). */

@@ -15,6 +15,7 @@ _LAZY = {
     "flow_matching_sample": "sampler", "crossfade_chunks": "sampler", "chunk_plan": "sampler",
     "sample_long": "sampler", "Sampler": "sampler", "channel_affine": "sampler",
     "load_latent_file": "io", "save_latent_file": "io", "load_stats": "io",
+    "Trainer": "train", "u_shaped_timestep_sampling": "train", "get_lr": "train", "GradScaler": "train",
 }
 __all__ = ["recipe"] + sorted(_LAZY)
 

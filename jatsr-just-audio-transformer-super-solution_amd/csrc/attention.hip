@@ -193,6 +193,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + frow;
     if (q < N) {
+      // training forward: log2-domain log-sum-exp of the scaled scores, P = exp2(s * scale_log2e - lse) in the backward
+      if (p.lse && fg == 0) p.lse[((int64_t)b * p.Hq + h) * N + q] = m_run[qt] + log2f(l);
       bf16_t* op = p.o + ((int64_t)b * N + q) * p.ldo + h * 64 + fg * 4;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -359,7 +361,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid((a.N + 64 * QT - 1) / (64 * QT), a.Hq, a.B);
   static const int kvb_env = getenv("JAT_ATTN_KVB") ? atoi(getenv("JAT_ATTN_KVB")) : 64;
   static const int group_env = getenv("JAT_ATTN_GROUP") ? atoi(getenv("JAT_ATTN_GROUP")) : 1;
-  if (group_env && a.N <= 128 && a.npad >= 128) {   // the sampler's shape: K/V staged once per KV head
+  if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse) {   // the sampler's shape: K/V staged once per KV head
     hipLaunchKernelGGL((attn_group_kernel<1, 8>), dim3(a.Hkv, a.B), dim3(512), 0, s, a);
   } else if (kvb_env == 64 || a.N <= 64) {
     hipLaunchKernelGGL((attn_fwd_kernel<QT, 64>), grid, dim3(256), 0, s, a);

@@ -14,52 +14,16 @@
 #include <unordered_map>
 #include <vector>
 
-#include "jat_kernels.h"
+#include "jat_internal.h"
 
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+int jat_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-#define HIPCHK(expr)                                                                                   \
-  do {                                                                                                 \
-    hipError_t e__ = (expr);                                                                           \
-    if (e__ != hipSuccess) return fail(JAT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
-                                       __FILE__, __LINE__);                                            \
-  } while (0)
-#define JCHK(expr)            \
-  do {                        \
-    int r__ = (expr);         \
-    if (r__ != JAT_OK) return r__; \
-  } while (0)
-
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-static constexpr int MAX_LEN = 2048;  // jat_audiosr_v3.py:361
-static constexpr int HEAD_DIM = 64;
-
-struct LayerW {
-  bf16_t *wqkv, *wo, *w1, *w2;  // [D+2kvD, D], [D, D], [mlp, D], [D, mlp]
-  bf16_t* wqkv_g = nullptr;     // group-major copy [Hkv][5*64 + 64 + 64][D] for the fused QKV+attention kernel (Hq/Hkv == 5)
-  float *norm1, *norm2, *b1, *b2;
-};
-
-struct jat_model {
-  jat_config cfg;
-  int D, depth, Hq, Hkv, kvD, mlp, bott, Cin, Cc, P, Kp, Fout;
-  bool loaded = false;
-  char* blob = nullptr;  // one device allocation holding every packed tensor
-  size_t blob_bytes = 0;
-  bf16_t *pe_w1, *pe_w2, *wada, *wfinal;
-  float *pe_b1, *pe_b2, *te_w1, *te_b1, *te_w2, *te_b2, *bada, *final_norm, *bfinal, *rope_cos, *rope_sin, *rope_invf;
-  std::vector<LayerW> layers;
-  // GEMM tile/pipeline variant per call site: qkv, out_proj, fc1, fc2, everything else (gemm.hip table)
-  int variants[5] = {-1, -1, -1, -1, -1};  // -1: choose by shape (pick_variant)
-  mutable int last_fold_np = 0;            // partial-sum slots per row written by the latest folding producer
-};
-enum { G_QKV = 0, G_OUT = 1, G_FC1 = 2, G_FC2 = 3, G_OTHER = 4 };
 
 // workspace carve-up for a forward over `B` batch rows of `ntok` tokens
 struct Workspace {
@@ -148,7 +112,11 @@ extern "C" void jat_model_destroy(jat_model* m) {
 
 extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, void* stream_) {
   if (!m || !named) return fail(JAT_E_INVALID, "null argument");
-  hipStream_t s = (hipStream_t)stream_;
+  return jat_pack_weights(m, named, n, (hipStream_t)stream_, true);
+}
+
+// build_tables == false: re-pack after an optimiser step (jat_train.cpp) — conversions only, no host synchronisation
+int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipStream_t s, bool build_tables) {
   std::unordered_map<std::string, const jat_tensor_ref*> by_name;
   for (int i = 0; i < n; ++i) by_name[named[i].name] = &named[i];
   const int D = m->D, kvD = m->kvD, mlp = m->mlp, bott = m->bott, depth = m->depth;
@@ -225,6 +193,7 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
       rc = fail(JAT_E_HIP, "memcpy failed for '%s'", name.c_str());
   };
   auto ones = [&](float* dst, int64_t numel) {
+    if (!build_tables) return;  // constants: written once at load time
     std::vector<float> h(numel, 1.0f);
     if (hipMemcpyAsync(dst, h.data(), numel * 4, hipMemcpyHostToDevice, s) != hipSuccess) rc = fail(JAT_E_HIP, "memcpy");
     (void)hipStreamSynchronize(s);
@@ -273,7 +242,7 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
 
   // RoPE tables in fp32 exactly as RoPE.__init__ builds them (jat_audiosr_v3.py:77-85); only the first half
   // of `emb = cat([freqs, freqs])` is distinct.
-  {
+  if (build_tables) {
     std::vector<float> hc((size_t)MAX_LEN * 32), hs((size_t)MAX_LEN * 32), hf(32);
     for (int i = 0; i < 32; ++i) {
       const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
@@ -289,7 +258,7 @@ extern "C" int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named,
     HIPCHK(hipMemcpyAsync(m->rope_invf, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
   }
-  HIPCHK(hipStreamSynchronize(s));
+  if (build_tables) HIPCHK(hipStreamSynchronize(s));
   m->loaded = true;
   return JAT_OK;
 }
@@ -341,8 +310,8 @@ static int pick_variant(int M, int N) {
 
 static int kTileN(int variant) { int bm, bn; gemm_variant_tile(variant, &bm, &bn); return bn; }
 
-static int gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, int M, int N,
-                int K, int epi, GemmArgs extra, hipStream_t s) {
+int jat_gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, int M, int N,
+             int K, int epi, GemmArgs extra, hipStream_t s) {
   GemmArgs a = extra;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
   int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N);
@@ -369,11 +338,7 @@ static int gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, cons
   if (e != hipSuccess) return fail(JAT_E_HIP, "gemm launch (M=%d N=%d K=%d epi=%d): %s", M, N, K, epi, hipGetErrorString(e));
   return JAT_OK;
 }
-#define KCHK(expr)                                                                            \
-  do {                                                                                        \
-    hipError_t e__ = (expr);                                                                  \
-    if (e__ != hipSuccess) return fail(JAT_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));   \
-  } while (0)
+#define gemm jat_gemm
 
 // t [B] -> t_emb [B,D] fp32 (+ bf16 silu(t_emb))  (t_embedder, jat_audiosr_v3.py:364-369)
 static int time_path(const jat_model* m, const Workspace& w, const float* t, int B, hipStream_t s) {

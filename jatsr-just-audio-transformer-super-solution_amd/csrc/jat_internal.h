@@ -1,0 +1,60 @@
+// Internals shared by the C-ABI translation units (jat_api.cpp: model / forward / sampler; jat_train.cpp: training step).
+#pragma once
+#include "../../include/jat_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "jat_kernels.h"
+
+int jat_fail(int code, const char* fmt, ...);
+#define fail jat_fail
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) return fail(JAT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                       __FILE__, __LINE__);                                            \
+  } while (0)
+#define JCHK(expr)            \
+  do {                        \
+    int r__ = (expr);         \
+    if (r__ != JAT_OK) return r__; \
+  } while (0)
+#define KCHK(expr)                                                                            \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) return fail(JAT_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));   \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static constexpr int MAX_LEN = 2048;  // jat_audiosr_v3.py:361
+static constexpr int HEAD_DIM = 64;
+
+struct LayerW {
+  bf16_t *wqkv, *wo, *w1, *w2;  // [D+2kvD, D], [D, D], [mlp, D], [D, mlp]
+  bf16_t* wqkv_g = nullptr;     // group-major copy [Hkv][5*64 + 64 + 64][D] for the fused QKV+attention kernel (Hq/Hkv == 5)
+  float *norm1, *norm2, *b1, *b2;
+};
+
+struct jat_model {
+  jat_config cfg;
+  int D, depth, Hq, Hkv, kvD, mlp, bott, Cin, Cc, P, Kp, Fout;
+  bool loaded = false;
+  char* blob = nullptr;  // one device allocation holding every packed tensor
+  size_t blob_bytes = 0;
+  bf16_t *pe_w1, *pe_w2, *wada, *wfinal;
+  float *pe_b1, *pe_b2, *te_w1, *te_b1, *te_w2, *te_b2, *bada, *final_norm, *bfinal, *rope_cos, *rope_sin, *rope_invf;
+  std::vector<LayerW> layers;
+  // GEMM tile/pipeline variant per call site: qkv, out_proj, fc1, fc2, everything else (gemm.hip table)
+  int variants[5] = {-1, -1, -1, -1, -1};  // -1: choose by shape (pick_variant)
+  mutable int last_fold_np = 0;            // partial-sum slots per row written by the latest folding producer
+};
+enum { G_QKV = 0, G_OUT = 1, G_FC1 = 2, G_FC2 = 3, G_OTHER = 4 };
+
+// C[M,N] = A[M,K] W[N,K]^T through the variant chooser / profiling bracket of jat_api.cpp
+int jat_gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const bf16_t* W, int64_t ldw, int M, int N, int K,
+             int epi, GemmArgs extra, hipStream_t s);
+// (re)pack the bf16 / fp32 device copies of the model from named fp32 tensors; sync_tables: also (re)build the RoPE tables
+int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipStream_t s, bool build_tables);

@@ -77,6 +77,7 @@ struct AttnArgs {
   int64_t ldq, ldk, ldo;
   int B, N, Hq, Hkv, npad;
   float scale_log2e; // (1/sqrt(64)) * log2(e)
+  float* lse;        // optional [B, Hq, N] fp32: log2-domain log-sum-exp per query row (training forward), else nullptr
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -111,3 +112,36 @@ hipError_t launch_channel_affine(const float* in, const float* mean, const float
                                  int C, int T, int inverse, hipStream_t s);
 hipError_t launch_crossfade_pair(const float* prev, int Tp, const float* cur, int Tc, int overlap,
                                  float* out, int rows, hipStream_t s);
+
+// ---- training step (train.hip): backward, loss, optimiser, data preparation -------------------------------------------
+hipError_t launch_transpose_bf16(const bf16_t* in, int64_t ld_in, int M, int C, bf16_t* out, int Mpad, hipStream_t s);
+hipError_t launch_rowsum_bf16(const bf16_t* x, int64_t ld, int R, int n, float* out, hipStream_t s);
+hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, hipStream_t s);
+hipError_t launch_gelu_bwd(const bf16_t* pre, bf16_t* d, int64_t n, hipStream_t s);
+hipError_t launch_resid_gate(const float* x_in, const bf16_t* y, const float* gate, int64_t gate_bstride, float* x_out,
+                             int M, int D, int ntok, hipStream_t s);
+int train_nchunk(int ntok);     // token chunks per sample of the column-reduction partials
+int train_red_blocks();         // blocks (= partial sums) of the scalar reductions
+hipError_t launch_gate_bwd(const float* dx, const bf16_t* y, const float* gate, int64_t gate_bstride, bf16_t* dy,
+                           float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, hipStream_t s);
+hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, const float* scale, int64_t mod_bstride,
+                           float* dx, int accumulate, float* part, float* dshift, float* dscale, int64_t dmod_bstride,
+                           float* dw, int B, int D, int ntok, int mode, hipStream_t s);
+hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
+                                const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
+                                int B, int N, int Hq, int Hkv, int npad, hipStream_t s);
+hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
+                           float loss_scale, hipStream_t s);
+hipError_t launch_grad_sqsum(const float* g, int64_t n, float* part, float* norm2, hipStream_t s);
+hipError_t launch_adamw(float* p, float* g, float* m, float* v, int64_t n, const float* norm2, float inv_scale,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
+hipError_t launch_small_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dW, float* db, int B, int N,
+                           int K, int silu_x, hipStream_t s);
+hipError_t launch_small_dx(const float* dy, int64_t ldy, const float* W, float* part, float* dx, int B, int N, int K,
+                           int accumulate, const float* silu_pre, hipStream_t s);
+hipError_t launch_silu_f32(const float* in, float* out, int64_t n, hipStream_t s);
+hipError_t launch_unpack_qkv_grad(const float* fused, float* gq, float* gk, float* gv, int D, int kvD, int K, hipStream_t s);
+hipError_t launch_flow_mix(const float* x, const float* noise, const float* t, float* z, int B, int64_t per_sample, hipStream_t s);
+hipError_t launch_cond_augment(float* cond, const float* noise, const float* std2, float ratio, const float* keep, int B,
+                               int64_t per_sample, hipStream_t s);
+hipError_t launch_tensor_std(const float* x, int64_t n, float* part, float* mean2, float* out2, hipStream_t s);

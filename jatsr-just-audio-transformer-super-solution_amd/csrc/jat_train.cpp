@@ -1,0 +1,394 @@
+// Training step of the DiT: the body of train_ddp_v3m2.py:533-622 split at its only
+// cross-device boundary.  jat_trainer_fwd_bwd = model(z_t, t, cond) -> mse_loss -> backward into a flat fp32 gradient
+// buffer; the caller all-reduces that buffer (RCCL) when world_size > 1; jat_trainer_optim = clip_grad_norm_ + AdamW +
+// re-pack of the bf16 operand copies.  Sequencing only: the arithmetic lives in gemm.hip / attention.hip /
+// elementwise.hip / train.hip.
+//
+// Every Linear runs its three GEMMs on gemm_bf16_kernel (C = A W^T, both operands K-contiguous):
+//   y  = x  W^T        A = x [M,in]          W = W   [out,in]
+//   dx = dy W          A = dy [M,out]        W = W^T [in,out]     (transposed bf16 copy, rebuilt after every update)
+//   dW = dy^T x        A = dy^T [out,Mpad]   W = x^T [in,Mpad]    (transpose_bf16_kernel, token axis zero-padded to 64)
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "jat_internal.h"
+
+namespace {
+
+struct TLayer {
+  float *x_mid, *lse;
+  bf16_t *xn1, *q, *k, *vt, *ao, *y_attn, *xn2, *h_pre, *h_post, *y_mlp;
+  bf16_t *wqkvT, *woT, *w1T, *w2T;
+  // gradient / master-parameter offsets (floats) into the flat buffers
+  int64_t o_n1, o_n2, o_q, o_k, o_v, o_o, o_w1, o_b1, o_w2, o_b2, o_ada_w, o_ada_b;
+};
+
+}  // namespace
+
+struct jat_trainer {
+  jat_model* m = nullptr;
+  int B = 0, T = 0, ntok = 0, M = 0, Mpad = 0, npad = 0;
+  float *P = nullptr, *G = nullptr, *m1 = nullptr, *m2 = nullptr;
+  int64_t total = 0;
+  std::vector<std::string> names;
+  std::vector<jat_tensor_ref> prefs;   // name -> pointer into P (for the re-pack)
+  char* blob = nullptr;
+  size_t blob_bytes = 0;
+  std::vector<float*> x;               // depth + 1 residual-stream snapshots [M, D]
+  std::vector<TLayer> L;
+  bf16_t *a_patch, *pe_pre, *pe_h, *xnf, *t_silu, *pe_w2T, *wfinalT;
+  float *e_sin, *u1, *t_h, *t_emb, *mod, *pred;
+  // backward scratch
+  float *dx, *dpred, *dmod, *part, *red_part, *scal, *delta, *dwqkv, *dsilu, *dt_emb, *du1, *small_part;
+  bf16_t *dy, *dh, *dxn, *dao, *dqkv, *tA, *tB, *dyf;
+  int64_t o_pe_w1, o_pe_b1, o_pe_w2, o_pe_b2, o_te_w1, o_te_b1, o_te_w2, o_te_b2, o_fn, o_wf, o_bf;
+  bool rms = true;
+};
+
+namespace {
+
+int repack(jat_trainer* tr, hipStream_t s) {
+  jat_model* m = tr->m;
+  JCHK(jat_pack_weights(m, tr->prefs.data(), (int32_t)tr->prefs.size(), s, false));
+  const int D = m->D, Nqkv = D + 2 * m->kvD;
+  for (int l = 0; l < m->depth; ++l) {
+    const LayerW& W = m->layers[l];
+    TLayer& L = tr->L[l];
+    KCHK(launch_transpose_bf16(W.wqkv, D, Nqkv, D, L.wqkvT, Nqkv, s));
+    KCHK(launch_transpose_bf16(W.wo, D, D, D, L.woT, D, s));
+    KCHK(launch_transpose_bf16(W.w1, D, m->mlp, D, L.w1T, m->mlp, s));
+    KCHK(launch_transpose_bf16(W.w2, m->mlp, D, m->mlp, L.w2T, D, s));
+  }
+  KCHK(launch_transpose_bf16(m->pe_w2, m->bott, D, m->bott, tr->pe_w2T, D, s));
+  KCHK(launch_transpose_bf16(m->wfinal, D, m->Fout, D, tr->wfinalT, m->Fout, s));
+  return JAT_OK;
+}
+
+// dW[out,in] = dY^T X and (optionally) db[out] = column sums of dY, from dY bf16 [M,out] and X bf16 [M,in]
+int weight_grad(jat_trainer* tr, const bf16_t* dY, int out, const bf16_t* X, int in, float* dW, float* db, hipStream_t s) {
+  KCHK(launch_transpose_bf16(dY, out, tr->M, out, tr->tA, tr->Mpad, s));
+  KCHK(launch_transpose_bf16(X, in, tr->M, in, tr->tB, tr->Mpad, s));
+  GemmArgs e{};
+  e.out = dW; e.ldo = in; e.ntok = out;
+  JCHK(jat_gemm(tr->m, G_OTHER, tr->tA, tr->Mpad, tr->tB, tr->Mpad, out, in, tr->Mpad, EPI_F32, e, s));
+  if (db) KCHK(launch_rowsum_bf16(tr->tA, tr->Mpad, out, tr->Mpad, db, s));
+  return JAT_OK;
+}
+
+// dX bf16 [M,in] = dY [M,out] W, with WT = W^T [in,out]
+int input_grad(jat_trainer* tr, const bf16_t* dY, int out, const bf16_t* WT, int in, bf16_t* dX, hipStream_t s) {
+  GemmArgs e{};
+  e.out = dX; e.ldo = in; e.ntok = tr->ntok;
+  return jat_gemm(tr->m, G_OTHER, dY, out, WT, out, tr->M, in, out, EPI_BF16, e, s);
+}
+
+int forward_train(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond, hipStream_t s) {
+  jat_model* m = tr->m;
+  const int B = tr->B, T = tr->T, ntok = tr->ntok, M = tr->M, D = m->D, Nqkv = D + 2 * m->kvD;
+  const int64_t mstride = (int64_t)m->depth * 6 * D;
+  // t_embedder (fp32; jat_audiosr_v3.py:364-369) with the pre-activation kept for the backward
+  KCHK(launch_time_sinusoid(t, tr->e_sin, B, D, s));
+  KCHK(launch_linear_f32(tr->e_sin, m->te_w1, m->te_b1, tr->u1, nullptr, B, D, D, 0, s));
+  KCHK(launch_silu_f32(tr->u1, tr->t_h, (int64_t)B * D, s));
+  KCHK(launch_linear_f32(tr->t_h, m->te_w2, m->te_b2, tr->t_emb, tr->t_silu, B, D, D, 0, s));
+  {
+    GemmArgs e{};
+    e.out = tr->mod; e.ldo = mstride; e.bias = m->bada; e.ntok = 1;
+    JCHK(jat_gemm(m, G_OTHER, tr->t_silu, D, m->wada, D, B, (int)mstride, D, EPI_F32, e, s));
+  }
+  KCHK(launch_patchify(z_t, x_cond, tr->a_patch, B, B, B, m->Cin, m->Cc, T, ntok, s));
+  {
+    GemmArgs e{};
+    e.out = tr->pe_pre; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok;
+    JCHK(jat_gemm(m, G_OTHER, tr->a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16, e, s));
+    KCHK(launch_gelu_bf16(tr->pe_pre, tr->pe_h, (int64_t)M * m->bott, s));
+    GemmArgs f{};
+    f.out = tr->x[0]; f.ldo = D; f.bias = m->pe_b2; f.ntok = ntok;
+    JCHK(jat_gemm(m, G_OTHER, tr->pe_h, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, f, s));
+  }
+  for (int l = 0; l < m->depth; ++l) {
+    const LayerW& W = m->layers[l];
+    TLayer& L = tr->L[l];
+    const float* mod = tr->mod + (int64_t)l * 6 * D;
+    KCHK(launch_norm_modulate(tr->x[l], W.norm1, mod + 0 * D, mod + 1 * D, mstride, L.xn1, M, D, ntok, m->cfg.norm_mode, s));
+    {
+      GemmArgs e{};
+      e.out = L.q; e.k_out = L.k; e.vt_out = L.vt; e.D = D; e.kvD = m->kvD; e.npad = tr->npad; e.ntok = ntok;
+      e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin; e.rope_inv_freq = m->rope_invf;
+      JCHK(jat_gemm(m, G_QKV, L.xn1, D, W.wqkv, D, M, Nqkv, D, EPI_QKV_ROPE, e, s));
+    }
+    {
+      AttnArgs a{};
+      a.q = L.q; a.k = L.k; a.vt = L.vt; a.o = L.ao; a.ldq = D; a.ldk = m->kvD; a.ldo = D;
+      a.B = B; a.N = ntok; a.Hq = m->Hq; a.Hkv = m->Hkv; a.npad = tr->npad;
+      a.scale_log2e = 0.125f * 1.4426950408889634f;
+      a.lse = L.lse;
+      KCHK(launch_attention(a, s));
+    }
+    {
+      GemmArgs e{};
+      e.out = L.y_attn; e.ldo = D; e.ntok = ntok;
+      JCHK(jat_gemm(m, G_OUT, L.ao, D, W.wo, D, M, D, D, EPI_BF16, e, s));
+    }
+    KCHK(launch_resid_gate(tr->x[l], L.y_attn, mod + 2 * D, mstride, L.x_mid, M, D, ntok, s));
+    KCHK(launch_norm_modulate(L.x_mid, W.norm2, mod + 3 * D, mod + 4 * D, mstride, L.xn2, M, D, ntok, m->cfg.norm_mode, s));
+    {
+      GemmArgs e{};
+      e.out = L.h_pre; e.ldo = m->mlp; e.bias = W.b1; e.ntok = ntok;
+      JCHK(jat_gemm(m, G_FC1, L.xn2, D, W.w1, D, M, m->mlp, D, EPI_BF16, e, s));
+      KCHK(launch_gelu_bf16(L.h_pre, L.h_post, (int64_t)M * m->mlp, s));
+      GemmArgs f{};
+      f.out = L.y_mlp; f.ldo = D; f.bias = W.b2; f.ntok = ntok;
+      JCHK(jat_gemm(m, G_FC2, L.h_post, m->mlp, W.w2, m->mlp, M, D, m->mlp, EPI_BF16, f, s));
+    }
+    KCHK(launch_resid_gate(L.x_mid, L.y_mlp, mod + 5 * D, mstride, tr->x[l + 1], M, D, ntok, s));
+  }
+  KCHK(launch_norm_modulate(tr->x[m->depth], m->final_norm, nullptr, nullptr, 0, tr->xnf, M, D, ntok, m->cfg.norm_mode, s));
+  {
+    GemmArgs e{};
+    e.out = tr->pred; e.bias = m->bfinal; e.ntok = ntok; e.C_out = m->Cin; e.T_orig = T;
+    JCHK(jat_gemm(m, G_OTHER, tr->xnf, D, m->wfinal, D, M, m->Fout, D, EPI_UNPATCH, e, s));
+  }
+  return JAT_OK;
+}
+
+int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipStream_t s) {
+  jat_model* m = tr->m;
+  const int B = tr->B, T = tr->T, ntok = tr->ntok, M = tr->M, D = m->D, Nqkv = D + 2 * m->kvD, mode = m->cfg.norm_mode;
+  const int64_t mstride = (int64_t)m->depth * 6 * D;
+  float* G = tr->G;
+  KCHK(launch_mse_grad(tr->pred, target, tr->dpred, tr->red_part, tr->scal, (int64_t)B * m->Cin * T, loss_scale, s));
+  // final layer: Linear (unpatchify^T is a patchify of dpred) and the un-modulated norm
+  KCHK(launch_patchify(tr->dpred, nullptr, tr->dyf, B, B, B, m->Cin, 0, T, ntok, s));
+  JCHK(input_grad(tr, tr->dyf, m->Fout, tr->wfinalT, D, tr->dxn, s));
+  JCHK(weight_grad(tr, tr->dyf, m->Fout, tr->xnf, D, G + tr->o_wf, G + tr->o_bf, s));
+  KCHK(launch_norm_bwd(tr->x[m->depth], tr->dxn, m->final_norm, nullptr, 0, tr->dx, 0, tr->part, nullptr, nullptr, 0,
+                       tr->rms ? G + tr->o_fn : nullptr, B, D, ntok, mode, s));
+  for (int l = m->depth - 1; l >= 0; --l) {
+    TLayer& L = tr->L[l];
+    const float* mod = tr->mod + (int64_t)l * 6 * D;
+    float* dmod = tr->dmod + (int64_t)l * 6 * D;
+    // x_out = x_mid + gate_mlp * mlp(norm2(x_mid) * (1 + scale_mlp) + shift_mlp)          jat_audiosr_v3.py:303-306
+    KCHK(launch_gate_bwd(tr->dx, L.y_mlp, mod + 5 * D, mstride, tr->dy, tr->part, dmod + 5 * D, mstride, B, D, ntok, s));
+    JCHK(input_grad(tr, tr->dy, D, L.w2T, m->mlp, tr->dh, s));
+    JCHK(weight_grad(tr, tr->dy, D, L.h_post, m->mlp, G + L.o_w2, G + L.o_b2, s));
+    KCHK(launch_gelu_bwd(L.h_pre, tr->dh, (int64_t)M * m->mlp, s));
+    JCHK(input_grad(tr, tr->dh, m->mlp, L.w1T, D, tr->dxn, s));
+    JCHK(weight_grad(tr, tr->dh, m->mlp, L.xn2, D, G + L.o_w1, G + L.o_b1, s));
+    KCHK(launch_norm_bwd(L.x_mid, tr->dxn, m->layers[l].norm2, mod + 4 * D, mstride, tr->dx, 1, tr->part, dmod + 3 * D,
+                         dmod + 4 * D, mstride, tr->rms ? G + L.o_n2 : nullptr, B, D, ntok, mode, s));
+    // x_mid = x_in + gate_msa * out_proj(attn(norm1(x_in) * (1 + scale_msa) + shift_msa))   :297-300
+    KCHK(launch_gate_bwd(tr->dx, L.y_attn, mod + 2 * D, mstride, tr->dy, tr->part, dmod + 2 * D, mstride, B, D, ntok, s));
+    JCHK(input_grad(tr, tr->dy, D, L.woT, D, tr->dao, s));
+    JCHK(weight_grad(tr, tr->dy, D, L.ao, D, G + L.o_o, nullptr, s));
+    KCHK(launch_attention_bwd(L.q, L.k, L.vt, L.ao, tr->dao, L.lse, tr->delta, tr->dqkv, m->rope_cos, m->rope_sin, B, ntok,
+                              m->Hq, m->Hkv, tr->npad, s));
+    JCHK(input_grad(tr, tr->dqkv, Nqkv, L.wqkvT, D, tr->dxn, s));
+    JCHK(weight_grad(tr, tr->dqkv, Nqkv, L.xn1, D, tr->dwqkv, nullptr, s));
+    KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, s));
+    KCHK(launch_norm_bwd(tr->x[l], tr->dxn, m->layers[l].norm1, mod + 1 * D, mstride, tr->dx, 1, tr->part, dmod + 0 * D,
+                         dmod + 1 * D, mstride, tr->rms ? G + L.o_n1 : nullptr, B, D, ntok, mode, s));
+  }
+  // patch embed: Linear(Kp -> bott) - GELU - Linear(bott -> D)   (jat_audiosr_v3.py:221-225); no gradient to the input
+  KCHK(launch_cast_bf16(tr->dx, tr->dy, (int64_t)M * D, s));
+  JCHK(input_grad(tr, tr->dy, D, tr->pe_w2T, m->bott, tr->dh, s));
+  JCHK(weight_grad(tr, tr->dy, D, tr->pe_h, m->bott, G + tr->o_pe_w2, G + tr->o_pe_b2, s));
+  KCHK(launch_gelu_bwd(tr->pe_pre, tr->dh, (int64_t)M * m->bott, s));
+  JCHK(weight_grad(tr, tr->dh, m->bott, tr->a_patch, m->Kp, G + tr->o_pe_w1, G + tr->o_pe_b1, s));
+  // adaLN modulation Linear(SiLU(t_emb)) of every block (:275-278), then the t_embedder MLP (:364-369); fp32, B rows
+  for (int l = 0; l < m->depth; ++l) {
+    TLayer& L = tr->L[l];
+    const float* dmod = tr->dmod + (int64_t)l * 6 * D;
+    KCHK(launch_small_dw(dmod, mstride, tr->t_emb, D, G + L.o_ada_w, G + L.o_ada_b, B, 6 * D, D, 1, s));
+    KCHK(launch_small_dx(dmod, mstride, tr->P + L.o_ada_w, tr->small_part, tr->dt_emb, B, 6 * D, D, l > 0,
+                         l == m->depth - 1 ? tr->t_emb : nullptr, s));
+  }
+  KCHK(launch_small_dw(tr->dt_emb, D, tr->t_h, D, G + tr->o_te_w2, G + tr->o_te_b2, B, D, D, 0, s));
+  KCHK(launch_small_dx(tr->dt_emb, D, tr->P + tr->o_te_w2, tr->small_part, tr->du1, B, D, D, 0, tr->u1, s));
+  KCHK(launch_small_dw(tr->du1, D, tr->e_sin, D, G + tr->o_te_w1, G + tr->o_te_b1, B, D, D, 0, s));
+  return JAT_OK;
+}
+
+}  // namespace
+
+extern "C" void jat_trainer_destroy(jat_trainer* tr) {
+  if (!tr) return;
+  if (tr->blob) (void)hipFree(tr->blob);
+  delete tr;
+}
+
+extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, int32_t n, float* params_flat,
+                                  float* grads_flat, float* exp_avg, float* exp_avg_sq, int64_t total, int32_t B,
+                                  int32_t T, void* stream, jat_trainer** out) {
+  if (!m || !params || !params_flat || !grads_flat || !exp_avg || !exp_avg_sq || !out)
+    return fail(JAT_E_INVALID, "null argument");
+  if (B <= 0 || T <= 0) return fail(JAT_E_INVALID, "B and T must be positive");
+  if (B > 32) return fail(JAT_E_INVALID, "per-rank batch %d > 32 is not supported by the adaLN backward", B);
+  if (total <= 0 || total % 4 != 0) return fail(JAT_E_INVALID, "flat buffer length must be a positive multiple of 4");
+  const int ntok = (T + 3) / 4;
+  if (ntok > MAX_LEN) return fail(JAT_E_SEQLEN, "Sequence length %d exceeds max_len %d", ntok, MAX_LEN);
+  hipStream_t s = (hipStream_t)stream;
+  jat_trainer* tr = new jat_trainer();
+  tr->m = m; tr->B = B; tr->T = T; tr->ntok = ntok; tr->M = B * ntok;
+  tr->Mpad = (int)align_up((size_t)tr->M, 64); tr->npad = (int)align_up((size_t)ntok, 64);
+  tr->P = params_flat; tr->G = grads_flat; tr->m1 = exp_avg; tr->m2 = exp_avg_sq; tr->total = total;
+  tr->rms = m->cfg.norm_mode == JAT_NORM_RMS_W;
+  const int D = m->D, depth = m->depth, mlp = m->mlp, bott = m->bott, kvD = m->kvD, Nqkv = D + 2 * kvD;
+  const int M = tr->M, Mpad = tr->Mpad;
+
+  // ---- parameter table: every tensor must lie inside the flat buffer, 16-B aligned, with the expected size ----
+  std::unordered_map<std::string, int64_t> off;
+  tr->names.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    const int64_t o = params[i].data - params_flat;
+    if (o < 0 || o + params[i].numel > total || o % 4 != 0) {
+      delete tr;
+      return fail(JAT_E_INVALID, "parameter '%s' is not a 16-byte aligned slice of the flat buffer", params[i].name);
+    }
+    tr->names.emplace_back(params[i].name);
+    off[tr->names.back()] = o;
+  }
+  tr->prefs.resize(n);
+  for (int i = 0; i < n; ++i) tr->prefs[i] = jat_tensor_ref{tr->names[i].c_str(), params[i].data, params[i].numel};
+  int rc = JAT_OK;
+  size_t used = 0;
+  auto need = [&](const std::string& name) -> int64_t {
+    auto it = off.find(name);
+    if (it == off.end()) { rc = fail(JAT_E_STATE, "missing parameter '%s'", name.c_str()); return 0; }
+    ++used;
+    return it->second;
+  };
+  tr->o_pe_w1 = need("patch_embed.proj.0.weight"); tr->o_pe_b1 = need("patch_embed.proj.0.bias");
+  tr->o_pe_w2 = need("patch_embed.proj.2.weight"); tr->o_pe_b2 = need("patch_embed.proj.2.bias");
+  tr->o_te_w1 = need("t_embedder.1.weight"); tr->o_te_b1 = need("t_embedder.1.bias");
+  tr->o_te_w2 = need("t_embedder.3.weight"); tr->o_te_b2 = need("t_embedder.3.bias");
+  tr->o_fn = tr->rms ? need("final_layer.0.weight") : 0;
+  tr->o_wf = need("final_layer.1.weight"); tr->o_bf = need("final_layer.1.bias");
+  tr->L.resize(depth);
+  for (int l = 0; l < depth; ++l) {
+    const std::string p = "blocks." + std::to_string(l) + ".";
+    TLayer& L = tr->L[l];
+    L.o_n1 = tr->rms ? need(p + "norm1.weight") : 0; L.o_n2 = tr->rms ? need(p + "norm2.weight") : 0;
+    L.o_q = need(p + "attn.q_proj.weight"); L.o_k = need(p + "attn.k_proj.weight"); L.o_v = need(p + "attn.v_proj.weight");
+    L.o_o = need(p + "attn.out_proj.weight");
+    L.o_w1 = need(p + "mlp.0.weight"); L.o_b1 = need(p + "mlp.0.bias");
+    L.o_w2 = need(p + "mlp.3.weight"); L.o_b2 = need(p + "mlp.3.bias");
+    L.o_ada_w = need(p + "adaLN_modulation.1.weight"); L.o_ada_b = need(p + "adaLN_modulation.1.bias");
+  }
+  if (rc == JAT_OK && used != (size_t)n)
+    rc = fail(JAT_E_INVALID, "%d parameters given, %zu belong to this model: every trainable tensor must be known", n, used);
+  if (rc != JAT_OK) { delete tr; return rc; }
+
+  // ---- one allocation: transposed weights, saved activations, backward scratch ----
+  for (int pass = 0; pass < 2; ++pass) {
+    size_t o = 0;
+    char* base = tr->blob;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += align_up(bytes, 256); return p; };
+    const size_t MD2 = (size_t)M * D * 2, MD4 = (size_t)M * D * 4;
+    tr->x.resize(depth + 1);
+    for (int l = 0; l <= depth; ++l) tr->x[l] = (float*)take(MD4);
+    for (int l = 0; l < depth; ++l) {
+      TLayer& L = tr->L[l];
+      L.x_mid = (float*)take(MD4);
+      L.lse = (float*)take((size_t)B * m->Hq * ntok * 4);
+      L.xn1 = (bf16_t*)take(MD2); L.q = (bf16_t*)take(MD2); L.k = (bf16_t*)take((size_t)M * kvD * 2);
+      L.vt = (bf16_t*)take((size_t)B * m->Hkv * HEAD_DIM * tr->npad * 2);
+      L.ao = (bf16_t*)take(MD2); L.y_attn = (bf16_t*)take(MD2); L.xn2 = (bf16_t*)take(MD2);
+      L.h_pre = (bf16_t*)take((size_t)M * mlp * 2); L.h_post = (bf16_t*)take((size_t)M * mlp * 2);
+      L.y_mlp = (bf16_t*)take(MD2);
+      L.wqkvT = (bf16_t*)take((size_t)D * Nqkv * 2); L.woT = (bf16_t*)take((size_t)D * D * 2);
+      L.w1T = (bf16_t*)take((size_t)D * mlp * 2); L.w2T = (bf16_t*)take((size_t)mlp * D * 2);
+    }
+    tr->a_patch = (bf16_t*)take((size_t)M * m->Kp * 2);
+    tr->pe_pre = (bf16_t*)take((size_t)M * bott * 2); tr->pe_h = (bf16_t*)take((size_t)M * bott * 2);
+    tr->xnf = (bf16_t*)take(MD2);
+    tr->t_silu = (bf16_t*)take((size_t)B * D * 2);
+    tr->pe_w2T = (bf16_t*)take((size_t)bott * D * 2); tr->wfinalT = (bf16_t*)take((size_t)D * m->Fout * 2);
+    tr->e_sin = (float*)take((size_t)B * D * 4); tr->u1 = (float*)take((size_t)B * D * 4);
+    tr->t_h = (float*)take((size_t)B * D * 4); tr->t_emb = (float*)take((size_t)B * D * 4);
+    tr->mod = (float*)take((size_t)B * depth * 6 * D * 4);
+    tr->pred = (float*)take((size_t)B * m->Cin * T * 4);
+    tr->dx = (float*)take(MD4); tr->dpred = (float*)take((size_t)B * m->Cin * T * 4);
+    tr->dmod = (float*)take((size_t)B * depth * 6 * D * 4);
+    tr->part = (float*)take((size_t)B * train_nchunk(ntok) * 3 * D * 4);
+    tr->red_part = (float*)take((size_t)train_red_blocks() * 4);
+    tr->scal = (float*)take(64);
+    tr->delta = (float*)take((size_t)B * m->Hq * ntok * 4);
+    tr->dwqkv = (float*)take((size_t)Nqkv * D * 4);
+    tr->dsilu = (float*)take((size_t)B * D * 4); tr->dt_emb = (float*)take((size_t)B * D * 4);
+    tr->du1 = (float*)take((size_t)B * D * 4);
+    tr->small_part = (float*)take((size_t)((6 * D + 63) / 64) * B * D * 4);
+    tr->dy = (bf16_t*)take(MD2); tr->dh = (bf16_t*)take((size_t)M * std::max(mlp, bott) * 2);
+    tr->dxn = (bf16_t*)take(MD2); tr->dao = (bf16_t*)take(MD2); tr->dqkv = (bf16_t*)take((size_t)M * Nqkv * 2);
+    tr->dyf = (bf16_t*)take((size_t)M * m->Fout * 2);
+    const int rowsA = std::max(std::max(m->Fout, Nqkv), std::max(mlp, std::max(D, bott)));
+    const int rowsB = std::max(std::max(m->Kp, mlp), std::max(D, bott));
+    tr->tA = (bf16_t*)take((size_t)rowsA * Mpad * 2); tr->tB = (bf16_t*)take((size_t)rowsB * Mpad * 2);
+    if (pass == 0) {
+      tr->blob_bytes = o;
+      if (hipMalloc((void**)&tr->blob, o) != hipSuccess) {
+        delete tr;
+        return fail(JAT_E_HIP, "hipMalloc of %zu bytes for the training workspace failed", o);
+      }
+      // zero once: the key padding of every V^T buffer must be 0 and is never written afterwards
+      if (hipMemsetAsync(tr->blob, 0, o, s) != hipSuccess) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "memset failed"); }
+    }
+  }
+  rc = repack(tr, s);
+  if (rc != JAT_OK) { jat_trainer_destroy(tr); return rc; }
+  if (hipStreamSynchronize(s) != hipSuccess) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "trainer setup failed"); }
+  *out = tr;
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_workspace_bytes(const jat_trainer* tr, size_t* out) {
+  if (!tr || !out) return fail(JAT_E_INVALID, "null argument");
+  *out = tr->blob_bytes;
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float* cond, const float* noise,
+                                   const float* cond_noise, float cond_noise_ratio, int32_t adaptive, const float* keep,
+                                   const float* t, float* z_t, void* stream) {
+  if (!tr || !hr_norm || !cond || !noise || !t || !z_t) return fail(JAT_E_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t per = (int64_t)tr->m->Cin * tr->T;
+  if (cond_noise && cond_noise_ratio > 0.f && adaptive)   // lr_norm.std().clamp(0.5, 2.0)  (train_ddp_v3m2.py:553-556)
+    KCHK(launch_tensor_std(cond, (int64_t)tr->B * tr->m->Cc * tr->T, tr->red_part, tr->scal + 8, tr->scal + 4, s));
+  if ((cond_noise && cond_noise_ratio > 0.f) || keep)
+    KCHK(launch_cond_augment(cond, cond_noise_ratio > 0.f ? cond_noise : nullptr, adaptive ? tr->scal + 4 : nullptr,
+                             cond_noise_ratio, keep, tr->B, (int64_t)tr->m->Cc * tr->T, s));
+  KCHK(launch_flow_mix(hr_norm, noise, t, z_t, tr->B, per, s));
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_fwd_bwd(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond,
+                                   const float* target, float loss_scale, float* loss_out, float* x_pred_out,
+                                   void* stream) {
+  if (!tr || !z_t || !t || !x_cond || !target) return fail(JAT_E_INVALID, "null argument");
+  if (!tr->m->loaded) return fail(JAT_E_STATE, "weights not loaded");
+  hipStream_t s = (hipStream_t)stream;
+  JCHK(forward_train(tr, z_t, t, x_cond, s));
+  JCHK(backward_train(tr, target, loss_scale, s));
+  if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, tr->scal, 4, hipMemcpyDeviceToDevice, s));
+  if (x_pred_out)
+    HIPCHK(hipMemcpyAsync(x_pred_out, tr->pred, (size_t)tr->B * tr->m->Cin * tr->T * 4, hipMemcpyDeviceToDevice, s));
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_optim(jat_trainer* tr, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 float max_grad_norm, float loss_scale, int32_t step, float* grad_norm_out, void* stream) {
+  if (!tr) return fail(JAT_E_INVALID, "null argument");
+  if (step < 1 || loss_scale <= 0.f) return fail(JAT_E_INVALID, "step must be >= 1 and loss_scale > 0");
+  hipStream_t s = (hipStream_t)stream;
+  KCHK(launch_grad_sqsum(tr->G, tr->total, tr->red_part, tr->scal + 2, s));
+  KCHK(launch_adamw(tr->P, tr->G, tr->m1, tr->m2, tr->total, tr->scal + 2, 1.0f / loss_scale, max_grad_norm, lr, beta1, beta2,
+                    eps, weight_decay, step, s));
+  if (grad_norm_out) HIPCHK(hipMemcpyAsync(grad_norm_out, tr->scal + 3, 4, hipMemcpyDeviceToDevice, s));
+  return repack(tr, s);
+}

@@ -1,0 +1,838 @@
+// Backward-pass and optimiser kernels of the training step (train_ddp_v3m2.py:533-622).
+// The three GEMMs of every Linear (y = x W^T, dx = dy W, dW = dy^T x) all run on gemm_bf16_kernel (gemm.hip): its
+// operands are K-contiguous, so dx uses a transposed bf16 weight copy and dW uses transposed activation copies made
+// by transpose_bf16_kernel.  Everything here is either HBM-bound row/column work or the attention backward.
+// All reductions are fixed-order (partials + a finishing kernel): no atomics, a step is bit-reproducible.
+#include "jat_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+__device__ __forceinline__ unsigned short f2bf_t(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f_t(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (unsigned)f2bf_t(f[2 * i]) | ((unsigned)f2bf_t(f[2 * i + 1]) << 16);
+  return v;
+}
+
+// ---- bf16 transpose: out[c][m] = in[m][c], m >= M zero-filled up to Mpad (the K dimension of a dW GEMM) ----------
+// 64 x 64 tiles through LDS; reads and writes are 128-B runs.
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int M, int C,
+                                                             bf16_t* __restrict__ out, int Mpad) {
+  __shared__ unsigned short tile[64][66];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass * 32 + (tid >> 3), ch = tid & 7;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (m0 + r < M) v = *(const u32x4_t*)(in + (int64_t)(m0 + r) * ld_in + c0 + ch * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tile[r][ch * 8 + 2 * i] = (unsigned short)(v[i] & 0xffffu);
+      tile[r][ch * 8 + 2 * i + 1] = (unsigned short)(v[i] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = pass * 32 + (tid >> 3), ch = tid & 7;   // output row c, 8 consecutive m
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = (unsigned)tile[ch * 8 + 2 * i][c] | ((unsigned)tile[ch * 8 + 2 * i + 1][c] << 16);
+    if (m0 + ch * 8 < Mpad) *(u32x4_t*)(out + (int64_t)(c0 + c) * Mpad + m0 + ch * 8) = v;
+  }
+}
+hipError_t launch_transpose_bf16(const bf16_t* in, int64_t ld_in, int M, int C, bf16_t* out, int Mpad, hipStream_t s) {
+  if (C % 64 != 0 || Mpad % 64 != 0 || Mpad < M) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(Mpad / 64, C / 64), dim3(256), 0, s, in, ld_in, M, C, out, Mpad);
+  return hipGetLastError();
+}
+
+// ---- row sums of a bf16 matrix [R][ld] over its first n columns -> fp32 [R]   (bias gradients from dY^T) -------
+__global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int R, int n,
+                                                          float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float acc = 0.f;
+  for (int c = lane * 8; c < n; c += 512) {   // n % 8 == 0
+    float f[8];
+    unpack8(*(const u32x4_t*)(x + (int64_t)row * ld + c), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += f[i];
+  }
+  acc = wave_sum_t(acc);
+  if (lane == 0) out[row] = acc;
+}
+hipError_t launch_rowsum_bf16(const bf16_t* x, int64_t ld, int R, int n, float* out, hipStream_t s) {
+  if (n % 8 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, ld, R, n, out);
+  return hipGetLastError();
+}
+
+// ---- GELU (erf form, nn.GELU default) forward on bf16 and its backward ------------------------------------------
+__device__ __forceinline__ float gelu_t(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_t(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__global__ void __launch_bounds__(256) gelu_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float f[8];
+  unpack8(*(const u32x4_t*)(in + i * 8), f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = gelu_t(f[j]);
+  *(u32x4_t*)(out + i * 8) = pack8(f);
+}
+// dpre = dpost * gelu'(pre), in place on dpost
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ d, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float f[8], g[8];
+  unpack8(*(const u32x4_t*)(pre + i * 8), f);
+  unpack8(*(const u32x4_t*)(d + i * 8), g);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] *= dgelu_t(f[j]);
+  *(u32x4_t*)(d + i * 8) = pack8(g);
+}
+hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, hipStream_t s) {
+  if (n % 8 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gelu_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, in, out, n / 8);
+  return hipGetLastError();
+}
+hipError_t launch_gelu_bwd(const bf16_t* pre, bf16_t* d, int64_t n, hipStream_t s) {
+  if (n % 8 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, pre, d, n / 8);
+  return hipGetLastError();
+}
+
+// ---- gated residual forward with the branch output kept: x_out = x_in + gate[b] * y   (jat_audiosr_v3.py:300,306) --
+__global__ void __launch_bounds__(256) resid_gate_kernel(const float* __restrict__ x_in, const bf16_t* __restrict__ y,
+                                                         const float* __restrict__ gate, int64_t gate_bstride,
+                                                         float* __restrict__ x_out, int M, int D, int ntok) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread = 8 columns
+  const int per_row = D / 8;
+  if (i >= (int64_t)M * per_row) return;
+  const int row = (int)(i / per_row), c = (int)(i % per_row) * 8;
+  const float* g = gate + (int64_t)(row / ntok) * gate_bstride + c;
+  float f[8];
+  unpack8(*(const u32x4_t*)(y + (int64_t)row * D + c), f);
+  const f32x4_t a0 = *(const f32x4_t*)(x_in + (int64_t)row * D + c), a1 = *(const f32x4_t*)(x_in + (int64_t)row * D + c + 4);
+  const f32x4_t g0 = *(const f32x4_t*)g, g1 = *(const f32x4_t*)(g + 4);
+  f32x4_t o0, o1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { o0[j] = a0[j] + g0[j] * f[j]; o1[j] = a1[j] + g1[j] * f[4 + j]; }
+  *(f32x4_t*)(x_out + (int64_t)row * D + c) = o0;
+  *(f32x4_t*)(x_out + (int64_t)row * D + c + 4) = o1;
+}
+hipError_t launch_resid_gate(const float* x_in, const bf16_t* y, const float* gate, int64_t gate_bstride, float* x_out,
+                             int M, int D, int ntok, hipStream_t s) {
+  const int64_t n = (int64_t)M * (D / 8);
+  hipLaunchKernelGGL(resid_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x_in, y, gate, gate_bstride,
+                     x_out, M, D, ntok);
+  return hipGetLastError();
+}
+
+// ---- backward of the gated residual: dy = bf16(dx * gate[b]);  dgate[b][n] = sum_tok dx * y -----------------------
+// grid (chunks of TOKC tokens, B); partial sums part[b][chunk][D]; finished by reduce_chunks_kernel.
+constexpr int TOKC = 16;
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ y,
+                                                       const float* __restrict__ gate, int64_t gate_bstride,
+                                                       bf16_t* __restrict__ dy, float* __restrict__ part, int D, int ntok) {
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int t0 = chunk * TOKC, t1 = min(t0 + TOKC, ntok);
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    const f32x4_t g = *(const f32x4_t*)(gate + (int64_t)b * gate_bstride + c);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = t0; t < t1; ++t) {
+      const int64_t row = (int64_t)b * ntok + t;
+      const f32x4_t d = *(const f32x4_t*)(dx + row * D + c);
+      const u32x2_t yy = *(const u32x2_t*)(y + row * D + c);
+      const float y0 = __builtin_bit_cast(float, yy[0] << 16), y1 = __builtin_bit_cast(float, yy[0] & 0xffff0000u);
+      const float y2 = __builtin_bit_cast(float, yy[1] << 16), y3 = __builtin_bit_cast(float, yy[1] & 0xffff0000u);
+      acc[0] += d[0] * y0; acc[1] += d[1] * y1; acc[2] += d[2] * y2; acc[3] += d[3] * y3;
+      u32x2_t o;
+      o[0] = (unsigned)f2bf_t(d[0] * g[0]) | ((unsigned)f2bf_t(d[1] * g[1]) << 16);
+      o[1] = (unsigned)f2bf_t(d[2] * g[2]) | ((unsigned)f2bf_t(d[3] * g[3]) << 16);
+      *(u32x2_t*)(dy + row * D + c) = o;
+    }
+    *(f32x4_t*)(part + ((int64_t)b * nchunk + chunk) * D + c) = acc;
+  }
+}
+// out[b*out_bstride + c] = sum_chunk part[(b*nchunk + chunk)*chunk_stride + c]   (sum_b: also over b, out has one row)
+__global__ void __launch_bounds__(256) reduce_chunks_kernel(const float* __restrict__ part, int nchunk, int64_t chunk_stride,
+                                                            float* __restrict__ out, int64_t out_bstride, int B, int ncols,
+                                                            int sum_b) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  if (sum_b) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b)
+      for (int k = 0; k < nchunk; ++k) acc += part[((int64_t)b * nchunk + k) * chunk_stride + c];
+    out[c] = acc;
+  } else {
+    const int b = blockIdx.y;
+    float acc = 0.f;
+    for (int k = 0; k < nchunk; ++k) acc += part[((int64_t)b * nchunk + k) * chunk_stride + c];
+    out[(int64_t)b * out_bstride + c] = acc;
+  }
+}
+int train_nchunk(int ntok) { return (ntok + TOKC - 1) / TOKC; }
+hipError_t launch_gate_bwd(const float* dx, const bf16_t* y, const float* gate, int64_t gate_bstride, bf16_t* dy,
+                           float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, hipStream_t s) {
+  const int nchunk = train_nchunk(ntok);
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(nchunk, B), dim3(256), 0, s, dx, y, gate, gate_bstride, dy, part, D, ntok);
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((D + 255) / 256, B), dim3(256), 0, s, part, nchunk, (int64_t)D, dgate,
+                     dgate_bstride, B, D, 0);
+  return hipGetLastError();
+}
+
+// ---- backward of y = norm(x) * w * (1 + scale[b]) + shift[b] ---------------------------------------------------------
+// mode 0 RMSNorm(+w): xh = x * rstd;  mode 1 LayerNorm(no affine): xh = (x - mu) * rstd.   g = dy * w * (1 + scale).
+//   dx += rstd * (g - [mode 1: mean(g)] - xh * mean(g * xh));  dshift[b] = sum_tok dy;  dscale[b] = sum_tok dy * xh * w;
+//   dw = sum_rows dy * (1 + scale) * xh.
+// One wave per row (row in registers), each wave walks the rows of its token chunk and keeps per-column partial sums;
+// the four waves of a block are combined through LDS.  part[b][chunk][3][D] -> reduce_chunks_kernel.
+template <int NCH>
+__global__ void __launch_bounds__(256) norm_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                       const float* __restrict__ w, const float* __restrict__ scale,
+                                                       int64_t mod_bstride, float* __restrict__ dx, float* __restrict__ part,
+                                                       int D, int ntok, int mode, int accumulate) {
+  extern __shared__ float red[];   // [4 waves][3][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int t0 = chunk * TOKC, t1 = min(t0 + TOKC, ntok);
+  constexpr int nch = NCH;
+  f32x4_t a_sh[NCH], a_sc[NCH], a_w[NCH], ww[NCH], sc1[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    a_sh[c] = a_sc[c] = a_w[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    ww[c] = sc1[c] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+    if (c < nch) {
+      if (mode == 0 && w) ww[c] = *(const f32x4_t*)(w + c * 256 + lane * 4);
+      if (scale) {
+        const f32x4_t s4 = *(const f32x4_t*)(scale + (int64_t)b * mod_bstride + c * 256 + lane * 4);
+        sc1[c] = f32x4_t{1.f + s4[0], 1.f + s4[1], 1.f + s4[2], 1.f + s4[3]};
+      }
+    }
+  }
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const int64_t row = (int64_t)b * ntok + t;
+    f32x4_t xv[NCH], gv[NCH], dv[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (c < nch) {
+        xv[c] = *(const f32x4_t*)(x + row * D + c * 256 + lane * 4);
+        const u32x2_t d2 = *(const u32x2_t*)(dy + row * D + c * 256 + lane * 4);
+        dv[c][0] = __builtin_bit_cast(float, d2[0] << 16); dv[c][1] = __builtin_bit_cast(float, d2[0] & 0xffff0000u);
+        dv[c][2] = __builtin_bit_cast(float, d2[1] << 16); dv[c][3] = __builtin_bit_cast(float, d2[1] & 0xffff0000u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1 += xv[c][j]; s2 += xv[c][j] * xv[c][j]; }
+      }
+    float mu = 0.f, rstd;
+    if (mode == 0) {
+      rstd = rsqrtf(wave_sum_t(s2) / (float)D + 1e-6f);
+    } else {
+      mu = wave_sum_t(s1) / (float)D;
+      float var = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (c < nch)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float e = xv[c][j] - mu; var += e * e; }
+      rstd = rsqrtf(wave_sum_t(var) / (float)D + 1e-6f);
+    }
+    float mg = 0.f, mgx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (c < nch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[c][j] - mu) * rstd;
+          const float g = dv[c][j] * ww[c][j] * sc1[c][j];
+          xv[c][j] = xh; gv[c][j] = g;
+          mg += g; mgx += g * xh;
+          a_sh[c][j] += dv[c][j];
+          a_sc[c][j] += dv[c][j] * xh * ww[c][j];
+          a_w[c][j] += dv[c][j] * sc1[c][j] * xh;
+        }
+    mg = mode == 1 ? wave_sum_t(mg) / (float)D : 0.f;
+    mgx = wave_sum_t(mgx) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (c < nch) {
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[c][j] - mg - xv[c][j] * mgx);
+        float* dp = dx + row * D + c * 256 + lane * 4;
+        if (accumulate) {
+          const f32x4_t old = *(const f32x4_t*)dp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += old[j];
+        }
+        *(f32x4_t*)dp = o;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    if (c < nch) {
+      *(f32x4_t*)(red + (wave * 3 + 0) * D + c * 256 + lane * 4) = a_sh[c];
+      *(f32x4_t*)(red + (wave * 3 + 1) * D + c * 256 + lane * 4) = a_sc[c];
+      *(f32x4_t*)(red + (wave * 3 + 2) * D + c * 256 + lane * 4) = a_w[c];
+    }
+  __syncthreads();
+  float* po = part + ((int64_t)b * nchunk + chunk) * 3 * D;
+  for (int i = threadIdx.x; i < 3 * D; i += 256)
+    po[i] = red[i] + red[3 * D + i] + red[6 * D + i] + red[9 * D + i];
+}
+// dshift/dscale: [B] rows with stride dmod_bstride (nullptr: skip); dw [D] (nullptr: skip).  part: B*nchunk*3*D floats.
+hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, const float* scale, int64_t mod_bstride,
+                           float* dx, int accumulate, float* part, float* dshift, float* dscale, int64_t dmod_bstride,
+                           float* dw, int B, int D, int ntok, int mode, hipStream_t s) {
+  if (D % 256 != 0 || D > 2048) return hipErrorInvalidValue;
+  const int nchunk = train_nchunk(ntok);
+#define NORM_BWD_CASE(NCH)                                                                                              \
+  case NCH: {                                                                                                           \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)norm_bwd_kernel<NCH>,                               \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 12 * NCH * 256 * 4); \
+    if (attr != hipSuccess) return attr;                                                                                \
+    hipLaunchKernelGGL(norm_bwd_kernel<NCH>, dim3(nchunk, B), dim3(256), (size_t)12 * D * 4, s, x, dy, w, scale,        \
+                       mod_bstride, dx, part, D, ntok, mode, accumulate);                                               \
+    break;                                                                                                              \
+  }
+  switch (D >> 8) {
+    NORM_BWD_CASE(1) NORM_BWD_CASE(2) NORM_BWD_CASE(3) NORM_BWD_CASE(4) NORM_BWD_CASE(5) NORM_BWD_CASE(6) NORM_BWD_CASE(7)
+    NORM_BWD_CASE(8)
+  }
+#undef NORM_BWD_CASE
+  const dim3 g((D + 255) / 256, B);
+  if (dshift)
+    hipLaunchKernelGGL(reduce_chunks_kernel, g, dim3(256), 0, s, part, nchunk, (int64_t)3 * D, dshift, dmod_bstride, B, D, 0);
+  if (dscale)
+    hipLaunchKernelGGL(reduce_chunks_kernel, g, dim3(256), 0, s, part + D, nchunk, (int64_t)3 * D, dscale, dmod_bstride, B, D, 0);
+  if (dw)
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part + 2 * D, nchunk, (int64_t)3 * D, dw,
+                       (int64_t)0, B, D, 1);
+  return hipGetLastError();
+}
+
+// ---- attention backward (GQA, no mask, no dropout; jat_audiosr_v3.py:164-181) ------------------------------------------
+// S = Q K^T / 8, P = softmax(S), O = P V.  With lse2 = log2-domain log-sum-exp saved by the forward and
+// delta_i = sum_d dO_id O_id:   P = exp2(S * c - lse2),  dP = dO V^T,  dS = P (dP - delta) / 8,
+//   dV = P^T dO,  dK = dS^T Q  (summed over the 5 query heads of the KV group),  dQ = dS K.
+// Two kernels so that every output has exactly one writer (no atomics): attn_bwd_dkv (one block per 64-key block of a
+// (batch, KV head), looping over its query heads and all query blocks) and attn_bwd_dq (one block per 64-query block
+// of a (batch, query head), looping over key blocks).  All five products are v_mfma_f32_16x16x32_bf16 over operand
+// tiles staged in LDS as [64][64] bf16 images with a 144-B row pitch (conflict-free ds_read_b128).  The inverse RoPE
+// rotation (transpose of jat_audiosr_v3.py:87-108, pair-interleaved feature order) is applied to dQ / dK on the way out.
+constexpr int AP = 72;   // LDS row pitch in bf16 elements
+struct AttnBwdArgs {
+  const bf16_t *q, *k, *vt, *dout;   // q, dout [M, ldq]; k [M, ldk]; vt [B, Hkv, 64, npad]
+  const float *lse, *delta;           // [B, Hq, N]
+  bf16_t* dqkv;                       // [M, ldg]: dq at column 0, dk at column D, dv at column D + kvD
+  const float *rope_cos, *rope_sin;   // [max_pos, 32]
+  int64_t ldq, ldk, ldg;
+  int B, N, Hq, Hkv, npad, D, kvD;
+  float scale_log2e, scale;
+};
+
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t ld, int r0, int N,
+                                           unsigned short (*dst)[AP], unsigned short (*dstT)[AP], int tid) {
+  // 64 rows x 64 bf16 (row r0 + r of `src`, rows >= N read as zero) -> dst[r][d] and optionally dstT[d][r]
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass * 32 + (tid >> 3), ch = tid & 7;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (r0 + r < N) v = *(const u32x4_t*)(src + (int64_t)(r0 + r) * ld + ch * 8);
+    *(u32x4_t*)&dst[r][ch * 8] = v;
+    if (dstT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dstT[ch * 8 + 2 * i][r] = (unsigned short)(v[i] & 0xffffu);
+        dstT[ch * 8 + 2 * i + 1][r] = (unsigned short)(v[i] >> 16);
+      }
+    }
+  }
+}
+// V^T [64 d][npad keys] (global) -> dst[j][d] for keys j0 .. j0+63 (always inside npad; padding keys are zero)
+__device__ __forceinline__ void stage_vt(const bf16_t* __restrict__ vt, int npad, int j0, unsigned short (*dst)[AP], int tid) {
+  const int d = tid >> 2, jc = (tid & 3) * 16;
+  const u32x4_t a = *(const u32x4_t*)(vt + (int64_t)d * npad + j0 + jc);
+  const u32x4_t b = *(const u32x4_t*)(vt + (int64_t)d * npad + j0 + jc + 8);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dst[jc + 2 * i][d] = (unsigned short)(a[i] & 0xffffu);
+    dst[jc + 2 * i + 1][d] = (unsigned short)(a[i] >> 16);
+    dst[jc + 8 + 2 * i][d] = (unsigned short)(b[i] & 0xffffu);
+    dst[jc + 8 + 2 * i + 1][d] = (unsigned short)(b[i] >> 16);
+  }
+}
+// acc[nt] (16 x 16 tile nt of a 16 x 64 strip) += X[xr0 + 0..15][0..63] * Y[16 nt + 0..15][0..63]^T
+__device__ __forceinline__ void strip_mma(unsigned short (*X)[AP], int xr0, unsigned short (*Y)[AP], f32x4_t* acc, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8_t a = *(const bf16x8_t*)&X[xr0 + fr][ks * 32 + fg * 8];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const bf16x8_t bb = *(const bf16x8_t*)&Y[nt * 16 + fr][ks * 32 + fg * 8];
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nt], 0, 0, 0);
+    }
+  }
+}
+// store a 16 x 64 fp32 strip (lane: rows 4 fg + r, column 16 nt + fr) as bf16 rows of `dst`, optionally through the
+// inverse RoPE rotation of the interleaved pair (2d', 2d'+1): x0' = c x0 + s x1, x1' = c x1 - s x0
+__device__ __forceinline__ void store_strip(const f32x4_t* acc, bf16_t* __restrict__ dst, int64_t ld, int row0, int nrows,
+                                            int pos0, const float* __restrict__ rc, const float* __restrict__ rs, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = fg * 4 + r;
+      float v = acc[nt][r];
+      if (rc) {
+        const float partner = __shfl_xor(v, 1);
+        const int pos = min(pos0 + lr, 2047), dp = (nt * 16 + fr) >> 1;
+        const float c = rc[pos * 32 + dp], sn = rs[pos * 32 + dp];
+        v = (fr & 1) ? c * v - sn * partner : c * v + sn * partner;
+      }
+      if (lr < nrows) dst[(int64_t)(row0 + lr) * ld + nt * 16 + fr] = f2bf_t(v);
+    }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_dkv[];   // 8 images of [64][AP]
+  typedef unsigned short (*img_t)[AP];
+  img_t sK = (img_t)(smem_dkv + 0 * 64 * AP), sV = (img_t)(smem_dkv + 1 * 64 * AP), sQ = (img_t)(smem_dkv + 2 * 64 * AP),
+        sDO = (img_t)(smem_dkv + 3 * 64 * AP), sQT = (img_t)(smem_dkv + 4 * 64 * AP), sDOT = (img_t)(smem_dkv + 5 * 64 * AP),
+        sPT = (img_t)(smem_dkv + 6 * 64 * AP), sDST = (img_t)(smem_dkv + 7 * 64 * AP);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int jb = blockIdx.x, g = blockIdx.y, b = blockIdx.z, N = p.N, G = p.Hq / p.Hkv;
+  const int j0 = jb * 64;
+  stage_rows(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, sK, nullptr, tid);
+  stage_vt(p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad, p.npad, j0, sV, tid);
+  f32x4_t dk[4], dv[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) dk[nt] = dv[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nib = (N + 63) / 64;
+  for (int hh = 0; hh < G; ++hh) {
+    const int h = g * G + hh;
+    const float* lse = p.lse + ((int64_t)b * p.Hq + h) * N;
+    const float* dl = p.delta + ((int64_t)b * p.Hq + h) * N;
+    for (int ib = 0; ib < nib; ++ib) {
+      const int i0 = ib * 64;
+      __syncthreads();   // previous iteration's LDS reads are done (also orders the K/V staging before first use)
+      stage_rows(p.q + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sQ, sQT, tid);
+      stage_rows(p.dout + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sDO, sDOT, tid);
+      float l2[4], de[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wave * 16 + fg * 4 + r;
+        l2[r] = i < N ? lse[i] : 0.f;
+        de[r] = i < N ? dl[i] : 0.f;
+      }
+      __syncthreads();
+      f32x4_t sacc[4], pacc[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) sacc[nt] = pacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      strip_mma(sQ, wave * 16, sK, sacc, lane);    // S[i][j]
+      strip_mma(sDO, wave * 16, sV, pacc, lane);   // dP[i][j]
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float pr[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[r] = exp2f(sacc[nt][r] * p.scale_log2e - l2[r]);
+          ds[r] = pr[r] * (pacc[nt][r] - de[r]) * p.scale;
+        }
+        u32x2_t a, d;
+        a[0] = (unsigned)f2bf_t(pr[0]) | ((unsigned)f2bf_t(pr[1]) << 16);
+        a[1] = (unsigned)f2bf_t(pr[2]) | ((unsigned)f2bf_t(pr[3]) << 16);
+        d[0] = (unsigned)f2bf_t(ds[0]) | ((unsigned)f2bf_t(ds[1]) << 16);
+        d[1] = (unsigned)f2bf_t(ds[2]) | ((unsigned)f2bf_t(ds[3]) << 16);
+        *(u32x2_t*)&sPT[nt * 16 + fr][wave * 16 + fg * 4] = a;    // P^T[j][i]
+        *(u32x2_t*)&sDST[nt * 16 + fr][wave * 16 + fg * 4] = d;   // dS^T[j][i]
+      }
+      __syncthreads();
+      strip_mma(sPT, wave * 16, sDOT, dv, lane);   // dV[j][d] += sum_i P^T[j][i] dO^T[d][i]
+      strip_mma(sDST, wave * 16, sQT, dk, lane);   // dK[j][d] += sum_i dS^T[j][i] Q^T[d][i]
+    }
+  }
+  const int nrows = min(16, N - (j0 + wave * 16));
+  bf16_t* base = p.dqkv + (int64_t)b * N * p.ldg;
+  store_strip(dk, base + p.D + g * 64, p.ldg, j0 + wave * 16, nrows, j0 + wave * 16, p.rope_cos, p.rope_sin, lane);
+  store_strip(dv, base + p.D + p.kvD + g * 64, p.ldg, j0 + wave * 16, nrows, 0, nullptr, nullptr, lane);
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned short sQ[64][AP], sDO[64][AP], sK[64][AP], sV[64][AP], sKT[64][AP],
+      sDS[64][AP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int ib = blockIdx.x, h = blockIdx.y, b = blockIdx.z, N = p.N, g = h / (p.Hq / p.Hkv);
+  const int i0 = ib * 64;
+  stage_rows(p.q + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sQ, nullptr, tid);
+  stage_rows(p.dout + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sDO, nullptr, tid);
+  const float* lse = p.lse + ((int64_t)b * p.Hq + h) * N;
+  const float* dl = p.delta + ((int64_t)b * p.Hq + h) * N;
+  float l2[4], de[4];   // per query column i = i0 + 16 nt + fr of the transposed tiles
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int i = i0 + nt * 16 + fr;
+    l2[nt] = i < N ? lse[i] : 0.f;
+    de[nt] = i < N ? dl[i] : 0.f;
+  }
+  f32x4_t dq[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) dq[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int njb = (N + 63) / 64;
+  for (int jb = 0; jb < njb; ++jb) {
+    const int j0 = jb * 64;
+    __syncthreads();
+    stage_rows(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, sK, sKT, tid);
+    stage_vt(p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad, p.npad, j0, sV, tid);
+    __syncthreads();
+    f32x4_t sacc[4], pacc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) sacc[nt] = pacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    strip_mma(sK, wave * 16, sQ, sacc, lane);    // S^T[j][i]
+    strip_mma(sV, wave * 16, sDO, pacc, lane);   // dP^T[j][i]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = exp2f(sacc[nt][r] * p.scale_log2e - l2[nt]);
+        ds[r] = pr * (pacc[nt][r] - de[nt]) * p.scale;
+      }
+      u32x2_t d;
+      d[0] = (unsigned)f2bf_t(ds[0]) | ((unsigned)f2bf_t(ds[1]) << 16);
+      d[1] = (unsigned)f2bf_t(ds[2]) | ((unsigned)f2bf_t(ds[3]) << 16);
+      *(u32x2_t*)&sDS[nt * 16 + fr][wave * 16 + fg * 4] = d;   // dS[i][j]
+    }
+    __syncthreads();
+    strip_mma(sDS, wave * 16, sKT, dq, lane);   // dQ[i][d] += sum_j dS[i][j] K^T[d][j]
+  }
+  const int nrows = min(16, N - (i0 + wave * 16));
+  store_strip(dq, p.dqkv + (int64_t)b * N * p.ldg + h * 64, p.ldg, i0 + wave * 16, nrows, i0 + wave * 16, p.rope_cos,
+              p.rope_sin, lane);
+}
+
+// delta[b][h][i] = sum_d dO[i][h*64+d] * O[i][h*64+d]
+__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         int64_t ld, float* __restrict__ delta, int B, int N, int Hq) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (row, head), head fastest
+  if (idx >= (int64_t)B * N * Hq) return;
+  const int h = (int)(idx % Hq);
+  const int64_t row = idx / Hq;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float a[8], d[8];
+    unpack8(*(const u32x4_t*)(o + row * ld + h * 64 + c * 8), a);
+    unpack8(*(const u32x4_t*)(dout + row * ld + h * 64 + c * 8), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += a[j] * d[j];
+  }
+  const int b = (int)(row / N), i = (int)(row % N);
+  delta[((int64_t)b * Hq + h) * N + i] = acc;
+}
+
+hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
+                                const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
+                                int B, int N, int Hq, int Hkv, int npad, hipStream_t s) {
+  if (Hq % Hkv != 0 || npad % 64 != 0 || npad < N || N > 2048) return hipErrorInvalidValue;
+  AttnBwdArgs a;
+  a.q = q; a.k = k; a.vt = vt; a.dout = dout; a.lse = lse; a.delta = delta; a.dqkv = dqkv;
+  a.rope_cos = rope_cos; a.rope_sin = rope_sin;
+  a.D = Hq * 64; a.kvD = Hkv * 64; a.ldq = a.D; a.ldk = a.kvD; a.ldg = a.D + 2 * a.kvD;
+  a.B = B; a.N = N; a.Hq = Hq; a.Hkv = Hkv; a.npad = npad;
+  a.scale = 0.125f; a.scale_log2e = 0.125f * 1.4426950408889634f;
+  const int64_t nd = (int64_t)B * N * Hq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, o, dout, (int64_t)a.D, delta, B, N, Hq);
+  const int nb = (N + 63) / 64;
+  constexpr int dkv_lds = 8 * 64 * AP * 2;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds);
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, Hkv, B), dim3(256), dkv_lds, s, a);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb, Hq, B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---- loss: mse_loss(pred, target) (mean over all elements) and its gradient ------------------------------------------
+// dpred = 2 (pred - target) / n * loss_scale; per-block partial sums of (pred - target)^2, finished in fixed order.
+__global__ void __launch_bounds__(256) mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       float* __restrict__ dpred, float* __restrict__ part, int64_t n,
+                                                       float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const f32x4_t a = *(const f32x4_t*)(pred + i), t = *(const f32x4_t*)(target + i);
+      f32x4_t d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float e = a[j] - t[j]; acc += e * e; d[j] = e * gscale; }
+      *(f32x4_t*)(dpred + i) = d;
+    } else {
+      for (int64_t k = i; k < n; ++k) { const float e = pred[k] - target[k]; acc += e * e; dpred[k] = e * gscale; }
+    }
+  }
+  acc = wave_sum_t(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// out[0] = scale * sum(part[0..n)); out[1] = sqrt(sum) (used by the gradient norm)
+__global__ void __launch_bounds__(256) finish_sum_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = (float)(red[0] * (double)scale); out[1] = (float)sqrt(red[0] * (double)scale); }
+}
+constexpr int RED_BLOCKS = 1024;
+int train_red_blocks() { return RED_BLOCKS; }
+hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
+                           float loss_scale, hipStream_t s) {
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, pred, target, dpred, part, n,
+                     2.0f * loss_scale / (float)n);
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f / (float)n, loss2);
+  return hipGetLastError();
+}
+
+// ---- global gradient norm + clip + AdamW (torch.nn.utils.clip_grad_norm_, torch.optim.AdamW semantics) ---------------
+__global__ void __launch_bounds__(256) sqsum_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {   // n % 4 == 0
+    const f32x4_t a = *(const f32x4_t*)(g + i);
+    acc += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+  }
+  acc = wave_sum_t(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// norm2[0] = sum g^2 of the SCALED gradients, norm2[1] = its square root.  inv_scale undoes the loss scaling.
+// A non-finite norm skips the update (GradScaler.step semantics, train_ddp_v3m2.py:618).
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, const float* __restrict__ norm2,
+                                                    float inv_scale, float max_norm, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt) {
+  const float total = norm2[1] * inv_scale;
+  if (!(total == total) || total > 3.0e38f) return;
+  float coef = inv_scale;
+  if (max_norm > 0.f) coef *= fminf(1.0f, max_norm / (total + 1e-6f));
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    f32x4_t pp = *(const f32x4_t*)(p + i), gg = *(const f32x4_t*)(g + i), mm = *(const f32x4_t*)(m + i), vv = *(const f32x4_t*)(v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * coef;
+      gg[j] = gr;
+      pp[j] *= 1.0f - lr * wd;
+      mm[j] = beta1 * mm[j] + (1.0f - beta1) * gr;
+      vv[j] = beta2 * vv[j] + (1.0f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pp[j] -= (lr / bc1) * (mm[j] / denom);
+    }
+    *(f32x4_t*)(p + i) = pp; *(f32x4_t*)(g + i) = gg; *(f32x4_t*)(m + i) = mm; *(f32x4_t*)(v + i) = vv;
+  }
+}
+hipError_t launch_grad_sqsum(const float* g, int64_t n, float* part, float* norm2, hipStream_t s) {
+  if (n % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sqsum_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, g, n, part);
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f, norm2);
+  return hipGetLastError();
+}
+hipError_t launch_adamw(float* p, float* g, float* m, float* v, int64_t n, const float* norm2, float inv_scale,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s) {
+  if (n % 4 != 0 || step < 1) return hipErrorInvalidValue;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(2048), dim3(256), 0, s, p, g, m, v, n, norm2, inv_scale, max_norm, lr, beta1, beta2,
+                     eps, wd, (float)bc1, (float)sqrt(bc2));
+  return hipGetLastError();
+}
+
+// ---- small-batch fp32 Linear backward (adaLN modulation and t_embedder: at most a few dozen rows) ----------------------
+// dW[n][k] = sum_b dy[b][n] * x[b][k]   (optionally x -> silu(x));   db[n] = sum_b dy[b][n]
+__global__ void __launch_bounds__(256) small_dw_kernel(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ x,
+                                                       int64_t ldx, float* __restrict__ dW, float* __restrict__ db, int B,
+                                                       int N, int K, int silu_x) {
+  const int n = blockIdx.x;
+  float bsum = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float xv = x[(int64_t)b * ldx + k];
+      if (silu_x) xv = xv / (1.0f + __expf(-xv));
+      acc += dy[(int64_t)b * ldy + n] * xv;
+    }
+    dW[(int64_t)n * K + k] = acc;
+  }
+  if (db && threadIdx.x == 0) {
+    for (int b = 0; b < B; ++b) bsum += dy[(int64_t)b * ldy + n];
+    db[n] = bsum;
+  }
+}
+// partial dx: part[split][b][k] = sum_{n in split} dy[b][n] * W[n][k];  B <= 32 per launch group
+__global__ void __launch_bounds__(256) small_dx_kernel(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ W,
+                                                       float* __restrict__ part, int B, int N, int K, int rows_per_split) {
+  const int k = blockIdx.x * 256 + threadIdx.x, split = blockIdx.y;
+  if (k >= K) return;
+  const int n0 = split * rows_per_split, n1 = min(n0 + rows_per_split, N);
+  float acc[32];
+#pragma unroll
+  for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const float wv = W[(int64_t)n * K + k];
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+      if (b < B) acc[b] += dy[(int64_t)b * ldy + n] * wv;
+  }
+#pragma unroll
+  for (int b = 0; b < 32; ++b)
+    if (b < B) part[((int64_t)split * B + b) * K + k] = acc[b];
+}
+// dx[b][k] (+)= sum_split part[split][b][k], optionally times silu'(pre[b][k])
+__global__ void __launch_bounds__(256) small_dx_finish_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ dx,
+                                                              int64_t BK, int accumulate, const float* __restrict__ silu_pre) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BK) return;
+  float acc = 0.f;
+  for (int sidx = 0; sidx < nsplit; ++sidx) acc += part[(int64_t)sidx * BK + i];
+  if (accumulate) acc += dx[i];
+  if (silu_pre) {
+    const float u = silu_pre[i], sg = 1.0f / (1.0f + __expf(-u));
+    acc *= sg * (1.0f + u * (1.0f - sg));
+  }
+  dx[i] = acc;
+}
+hipError_t launch_small_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dW, float* db, int B, int N,
+                           int K, int silu_x, hipStream_t s) {
+  hipLaunchKernelGGL(small_dw_kernel, dim3(N), dim3(256), 0, s, dy, ldy, x, ldx, dW, db, B, N, K, silu_x);
+  return hipGetLastError();
+}
+// part must hold nsplit * B * K floats with nsplit = ceil(N / 64)
+hipError_t launch_small_dx(const float* dy, int64_t ldy, const float* W, float* part, float* dx, int B, int N, int K,
+                           int accumulate, const float* silu_pre, hipStream_t s) {
+  if (B > 32) return hipErrorInvalidValue;
+  const int rows = 64, nsplit = (N + rows - 1) / rows;
+  hipLaunchKernelGGL(small_dx_kernel, dim3((K + 255) / 256, nsplit), dim3(256), 0, s, dy, ldy, W, part, B, N, K, rows);
+  const int64_t BK = (int64_t)B * K;
+  hipLaunchKernelGGL(small_dx_finish_kernel, dim3((unsigned)((BK + 255) / 256)), dim3(256), 0, s, part, nsplit, dx, BK,
+                     accumulate, silu_pre);
+  return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) silu_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float u = in[i]; out[i] = u / (1.0f + __expf(-u)); }
+}
+hipError_t launch_silu_f32(const float* in, float* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(silu_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
+
+// ---- gradient of the fused, pair-interleaved [Wq; Wk; Wv] back to the reference's three tensors -------------------------
+// fused row (h*64 + 2d + e) of the q / k part holds reference row (h*64 + d + 32e)   (elementwise.hip cast_bf16_rope_rows)
+__global__ void __launch_bounds__(256) unpack_qkv_grad_kernel(const float* __restrict__ fused, float* __restrict__ gq,
+                                                              float* __restrict__ gk, float* __restrict__ gv, int D, int kvD,
+                                                              int K) {
+  const int r = blockIdx.x;   // fused row
+  float* dst;
+  if (r < D + kvD) {
+    const int base = r < D ? 0 : D, lr = r - base, h = lr >> 6, w = lr & 63;
+    const int ref = h * 64 + (w >> 1) + 32 * (w & 1);
+    dst = (r < D ? gq : gk) + (int64_t)ref * K;
+  } else {
+    dst = gv + (int64_t)(r - D - kvD) * K;
+  }
+  for (int k = threadIdx.x * 4; k < K; k += 1024) *(f32x4_t*)(dst + k) = *(const f32x4_t*)(fused + (int64_t)r * K + k);
+}
+hipError_t launch_unpack_qkv_grad(const float* fused, float* gq, float* gk, float* gv, int D, int kvD, int K, hipStream_t s) {
+  if (K % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(unpack_qkv_grad_kernel, dim3(D + 2 * kvD), dim3(256), 0, s, fused, gq, gk, gv, D, kvD, K);
+  return hipGetLastError();
+}
+
+// ---- data preparation of the step (train_ddp_v3m2.py:548-579) -----------------------------------------------------------
+// z_t = t[b] * x + (1 - t[b]) * noise
+__global__ void __launch_bounds__(256) flow_mix_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                       const float* __restrict__ t, float* __restrict__ z, int64_t per_sample,
+                                                       int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float tv = t[i / per_sample];
+  z[i] = tv * x[i] + (1.0f - tv) * noise[i];
+}
+hipError_t launch_flow_mix(const float* x, const float* noise, const float* t, float* z, int B, int64_t per_sample, hipStream_t s) {
+  const int64_t n = (int64_t)B * per_sample;
+  hipLaunchKernelGGL(flow_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, noise, t, z, per_sample, n);
+  return hipGetLastError();
+}
+// cond = (cond + noise * (ratio * clamp(std, 0.5, 2))) * keep[b];  std2[1] = unbiased std of cond (device scalar pair)
+__global__ void __launch_bounds__(256) cond_augment_kernel(float* __restrict__ cond, const float* __restrict__ noise,
+                                                           const float* __restrict__ std2, float ratio,
+                                                           const float* __restrict__ keep, int64_t per_sample, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = cond[i];
+  if (noise) v += noise[i] * (ratio * (std2 ? fminf(fmaxf(std2[1], 0.5f), 2.0f) : 1.0f));
+  cond[i] = v * (keep ? keep[i / per_sample] : 1.0f);
+}
+hipError_t launch_cond_augment(float* cond, const float* noise, const float* std2, float ratio, const float* keep, int B,
+                               int64_t per_sample, hipStream_t s) {
+  const int64_t n = (int64_t)B * per_sample;
+  hipLaunchKernelGGL(cond_augment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cond, noise, std2, ratio, keep,
+                     per_sample, n);
+  return hipGetLastError();
+}
+// unbiased standard deviation of a tensor (torch.Tensor.std()): two fixed-order passes (mean, then centred squares)
+__global__ void __launch_bounds__(256) moment_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ mean2,
+                                                     float* __restrict__ part) {
+  __shared__ float red[4];
+  const float mu = mean2 ? mean2[0] : 0.f;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float e = x[i] - mu;
+    acc += mean2 ? e * e : e;
+  }
+  acc = wave_sum_t(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// out2[0] = variance (unbiased), out2[1] = std; mean2 is scratch (2 floats)
+hipError_t launch_tensor_std(const float* x, int64_t n, float* part, float* mean2, float* out2, hipStream_t s) {
+  if (n < 2) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(moment_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, x, n, (const float*)nullptr, part);
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f / (float)n, mean2);
+  hipLaunchKernelGGL(moment_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, x, n, (const float*)mean2, part);
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f / (float)(n - 1), out2);
+  return hipGetLastError();
+}

@@ -197,6 +197,7 @@ class DiTBlock_GQA(nn.Module, _PackedMixin):
                                  nn.Linear(mlp_hidden_dim, hidden_size), nn.Dropout(dropout))
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
         self.drop_path = nn.Identity()  # eval-mode identity (jat_audiosr_v3.py:45)
+        self.dropout_rate, self.drop_path_rate = float(dropout), float(drop_path)   # training-only (jatsr_amd.train)
         self.hidden_size, self.num_q_heads, self.num_kv_heads = hidden_size, num_q_heads, num_kv_heads
         self.mlp_hidden = mlp_hidden_dim
         self._owner = None
@@ -303,8 +304,9 @@ class JaT_AudioSR_V3(nn.Module, _PackedMixin):
         self.t_embedder = nn.Sequential(TimeEmbedding(hidden_size), nn.Linear(hidden_size, hidden_size), nn.SiLU(),
                                         nn.Linear(hidden_size, hidden_size))
         self.blocks = nn.ModuleList([
-            DiTBlock_GQA(hidden_size, num_q_heads, num_kv_heads, mlp_ratio, dropout=dropout, norm=self._NORM)
-            for _ in range(depth)])
+            DiTBlock_GQA(hidden_size, num_q_heads, num_kv_heads, mlp_ratio, dropout=dropout, norm=self._NORM,
+                         drop_path=(drop_path_rate * i / (depth - 1) if depth > 1 else 0.0))   # linspace(0, rate, depth), :372-377
+            for i in range(depth)])
         patch_out_dim = patch_len * input_channels
         if self._NORM == "rms":
             self.final_layer = nn.Sequential(_NormHolder(hidden_size), nn.Linear(hidden_size, patch_out_dim))

@@ -1,0 +1,263 @@
+"""Training step on MI355X — the loop body of reference `train_ddp_v3m2.py:533-622`.
+
+    trainer = Trainer(model, batch_size=28, frames=1378)            # model: jatsr_amd.JaT_AudioSR_V3 on the GPU
+    for hr, lr in loader:                                           # raw latents [B, 1024, T]
+        stats = trainer.train_step(hr, lr, hr_mean, hr_std, lr_mean, lr_std)
+
+One process per GPU; the only collective is the gradient all-reduce between `jat_trainer_fwd_bwd` and
+`jat_trainer_optim` (the reference's DDP hook, train_ddp_v3m2.py:486,610), issued on ONE flat fp32 buffer.  The host
+code below owns the hyper-parameters and the RNG draws (torch generators: data, not arithmetic); everything numeric —
+normalisation, noise mix, forward, loss, backward, clip, AdamW — runs in the HIP library (include/jat_hip.h).
+
+Not implemented: Dropout / DropPath (jat_audiosr_v3.py:38-64,139,269-271) — `Trainer` refuses a model constructed
+with non-zero rates unless `allow_missing_regularisers=True`, in which case the step is the reference's with both at 0.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+ALIGN = 64   # floats: every tensor starts on a 256-B boundary of the flat buffers
+
+
+def u_shaped_timestep_sampling(batch_size, device, alpha=0.5, generator=None, u=None):
+    """== u_shaped_timestep_sampling (train_ddp_v3m2.py:164-172).  `u` injects the uniform draws (tests)."""
+    if u is None:
+        u = torch.rand(batch_size, device=device, generator=generator)
+    return torch.where(u < 0.5, (2 * u) ** alpha / 2, 1 - ((2 * (1 - u)) ** alpha) / 2)
+
+
+def get_lr(step, total_steps, warmup_steps, base_lr):
+    """== get_lr (train_ddp_v3m2.py:427-432): linear warm-up, then cosine to zero."""
+    if step < warmup_steps:
+        return base_lr * (step / max(1, warmup_steps))
+    progress = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    return base_lr * 0.5 * (1.0 + math.cos(math.pi * progress))
+
+
+def flat_layout(named_shapes):
+    """[(name, shape)] -> ([(name, offset, numel, shape)], total) with ALIGN-float alignment; total % ALIGN == 0."""
+    out, off = [], 0
+    for name, shape in named_shapes:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        out.append((name, off, n, tuple(shape)))
+        off += (n + ALIGN - 1) // ALIGN * ALIGN
+    return out, off
+
+
+class GradScaler:
+    """The subset of torch.amp.GradScaler the trainer relies on (train_ddp_v3m2.py:435,610-619): a loss scale that is
+    halved when a step's gradients are non-finite (the step is skipped) and doubled after `growth_interval` good steps."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.enabled = enabled
+        self._good = 0
+
+    def update(self, found_inf: bool):
+        if not self.enabled:
+            return
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+
+    def state_dict(self):
+        return dict(scale=self.scale, growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
+                    growth_interval=self.growth_interval, _growth_tracker=self._good)
+
+    def load_state_dict(self, sd):
+        self.scale = float(sd["scale"])
+        self._good = int(sd.get("_growth_tracker", 0))
+
+
+def allreduce_mean_(flat, group=None):
+    """Sum `flat` over the ranks of `group` in place and return the divisor the caller still has to apply (the
+    world size): the division is folded into the optimiser's unscale factor instead of a second pass over 3 GB."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return world
+
+
+class Trainer:
+    """One rank of the reference training loop.  Hyper-parameter names and defaults are TrainConfig's
+    (train_ddp_v3m2.py:55-101)."""
+
+    def __init__(self, model, batch_size, frames, lr=5e-5, weight_decay=0.1, betas=(0.9, 0.999), eps=1e-8,
+                 grad_clip=1.0, cfg_dropout_prob=0.1, condition_noise_ratio=0.02, use_adaptive_noise=True,
+                 warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None,
+                 allow_missing_regularisers=False):
+        L.require_gpu()
+        rates = [getattr(b, "dropout_rate", 0.0) for b in model.blocks] + [getattr(b, "drop_path_rate", 0.0) for b in model.blocks]
+        if any(r > 0 for r in rates) and not allow_missing_regularisers:
+            raise NotImplementedError("Dropout / DropPath are not implemented in the HIP training step; construct the "
+                                      "model with dropout=0, drop_path_rate=0 or pass allow_missing_regularisers=True")
+        self.model = model
+        self.B, self.T = int(batch_size), int(frames)
+        self.base_lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.grad_clip = grad_clip
+        self.cfg_dropout_prob, self.condition_noise_ratio = cfg_dropout_prob, condition_noise_ratio
+        self.use_adaptive_noise = use_adaptive_noise
+        self.warmup_steps, self.total_steps = warmup_steps, total_steps
+        self.scaler = GradScaler(enabled=use_grad_scaler)
+        self.group = process_group
+        self.global_step = 0
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise L.JatError("move the model to the GPU first (.to('cuda')); there is no CPU fallback")
+        self.device = dev
+        self.gen = torch.Generator(device=dev)
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        # ---- flat fp32 buffers; the model's parameters become views of `params` --------------------------------
+        named = [(k, p) for k, p in model.named_parameters()]
+        self.layout, total = flat_layout([(k, p.shape) for k, p in named])
+        self.params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        for (k, p), (_, off, n, shape) in zip(named, self.layout):
+            view = self.params[off:off + n].view(shape)
+            view.copy_(p.data.float())
+            p.data = view
+        h = model._get_handle()          # packs the (now flat-backed) weights
+        self._handle = h
+        refs = (L.JatTensorRef * len(self.layout))()
+        self._keep = []
+        for i, (k, off, n, _) in enumerate(self.layout):
+            kb = k.encode()
+            self._keep.append(kb)
+            refs[i] = L.JatTensorRef(kb, self.params.data_ptr() + 4 * off, n)
+        self.ptr = C.c_void_p()
+        L.check(L.lib().jat_trainer_create(h.ptr, refs, len(self.layout), L.ptr(self.params), L.ptr(self.grads),
+                                           L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), total, self.B, self.T,
+                                           L.stream_ptr(), C.byref(self.ptr)))
+        self._scal = torch.zeros(2, dtype=torch.float32, device=dev)   # loss, scaled grad norm
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                L.lib().jat_trainer_destroy(self.ptr)
+        except Exception:
+            pass
+
+    # -- views -------------------------------------------------------------------------------------------------
+    def grad(self, name):
+        """Gradient of the named parameter as a view of the flat buffer (after `forward_backward`)."""
+        for k, off, n, shape in self.layout:
+            if k == name:
+                return self.grads[off:off + n].view(shape)
+        raise KeyError(name)
+
+    def workspace_bytes(self):
+        out = C.c_size_t()
+        L.check(L.lib().jat_trainer_workspace_bytes(self.ptr, C.byref(out)))
+        return out.value
+
+    # -- the step, in the reference's order -------------------------------------------------------------------------
+    def prepare(self, hr_norm, lr_norm, noise=None, cond_noise=None, cfg_mask=None, t=None):
+        """train_ddp_v3m2.py:548-579 on normalised latents.  Draws whatever is not injected.  Returns (z_t, t, cond)."""
+        B = self.B
+        if t is None:
+            t = u_shaped_timestep_sampling(B, self.device, generator=self.gen)
+        if noise is None:
+            noise = torch.randn(hr_norm.shape, device=self.device, generator=self.gen)
+        if cond_noise is None and self.condition_noise_ratio > 0:
+            cond_noise = torch.randn(lr_norm.shape, device=self.device, generator=self.gen)
+        if cfg_mask is None:
+            cfg_mask = torch.rand(B, device=self.device, generator=self.gen) < self.cfg_dropout_prob
+        keep = (~cfg_mask.to(self.device).bool()).float().contiguous()
+        cond = lr_norm.contiguous().clone()
+        z_t = torch.empty_like(hr_norm)
+        t = t.to(self.device, torch.float32).contiguous()
+        L.check(L.lib().jat_trainer_prepare(self.ptr, L.ptr(hr_norm.contiguous()), L.ptr(cond), L.ptr(noise.contiguous()),
+                                            L.ptr(cond_noise.contiguous()) if cond_noise is not None else None,
+                                            float(self.condition_noise_ratio if cond_noise is not None else 0.0),
+                                            int(self.use_adaptive_noise), L.ptr(keep), L.ptr(t), L.ptr(z_t), L.stream_ptr()))
+        return z_t, t, cond
+
+    def forward_backward(self, z_t, t, cond, target, want_pred=False):
+        """pred = model(z_t, t, cond); loss = mse_loss(pred, target); backward -> self.grads (scaled by scaler.scale)."""
+        for x in (z_t, cond, target):
+            if tuple(x.shape) != (self.B, self.model.input_channels, self.T) or x.dtype != torch.float32 or not x.is_cuda:
+                raise ValueError(f"expected fp32 CUDA [{self.B}, {self.model.input_channels}, {self.T}], got "
+                                 f"{tuple(x.shape)} {x.dtype} on {x.device}")
+        pred = torch.empty_like(z_t) if want_pred else None
+        L.check(L.lib().jat_trainer_fwd_bwd(self.ptr, L.ptr(z_t.contiguous()), L.ptr(t.contiguous()), L.ptr(cond.contiguous()),
+                                            L.ptr(target.contiguous()), float(self.scaler.scale), L.ptr(self._scal),
+                                            L.ptr(pred) if want_pred else None, L.stream_ptr()))
+        return pred
+
+    def optimizer_step(self, lr=None):
+        """All-reduce, unscale, clip_grad_norm_(grad_clip), AdamW, re-pack.  Returns (loss, grad_norm) as floats —
+        the one host synchronisation of the step, like the reference's `.item()` calls (train_ddp_v3m2.py:615,622)."""
+        world = allreduce_mean_(self.grads, self.group)
+        if lr is None:
+            lr = get_lr(self.global_step, self.total_steps, self.warmup_steps, self.base_lr) if self.total_steps else self.base_lr
+        scale = self.scaler.scale * world
+        L.check(L.lib().jat_trainer_optim(self.ptr, float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                          float(self.weight_decay), float(self.grad_clip or 0.0), float(scale),
+                                          self.global_step + 1, C.c_void_p(self._scal.data_ptr() + 4), L.stream_ptr()))
+        loss, gnorm = self._scal.tolist()
+        gnorm /= scale
+        found_inf = not math.isfinite(gnorm)
+        self.scaler.update(found_inf)
+        if not found_inf:
+            self.global_step += 1
+        self.last_lr = lr
+        return loss, gnorm
+
+    def train_step(self, hr, lr, hr_mean, hr_std, lr_mean, lr_std):
+        """Raw latents in, one optimisation step (train_ddp_v3m2.py:533-622).  Returns dict(loss, grad_norm, lr)."""
+        from .sampler import channel_affine
+        hr_norm = channel_affine(hr.to(self.device, torch.float32), hr_mean, hr_std)
+        lr_norm = channel_affine(lr.to(self.device, torch.float32), lr_mean, lr_std)
+        z_t, t, cond = self.prepare(hr_norm, lr_norm)
+        self.forward_backward(z_t, t, cond, hr_norm)
+        loss, gnorm = self.optimizer_step()
+        return dict(loss=loss, grad_norm=gnorm, lr=self.last_lr, step=self.global_step)
+
+    # -- checkpoint egress / ingest in the reference's layout (train_ddp_v3m2.py:747-770, 443-500) ----------------------
+    def optimizer_state_dict(self):
+        """torch.optim.AdamW.state_dict() layout, so that the reference trainer can resume from it."""
+        state = {}
+        for i, (k, off, n, shape) in enumerate(self.layout):
+            state[i] = dict(step=torch.tensor(float(self.global_step)),
+                            exp_avg=self.exp_avg[off:off + n].view(shape).clone(),
+                            exp_avg_sq=self.exp_avg_sq[off:off + n].view(shape).clone())
+        group = dict(lr=getattr(self, "last_lr", self.base_lr), betas=tuple(self.betas), eps=self.eps,
+                     weight_decay=self.weight_decay, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                     differentiable=False, fused=None, params=list(range(len(self.layout))))
+        return dict(state=state if self.global_step > 0 else {}, param_groups=[group])
+
+    def load_optimizer_state_dict(self, sd):
+        for i, (k, off, n, shape) in enumerate(self.layout):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.exp_avg[off:off + n].view(shape).copy_(st["exp_avg"].to(self.device, torch.float32))
+            self.exp_avg_sq[off:off + n].view(shape).copy_(st["exp_avg_sq"].to(self.device, torch.float32))
+            self.global_step = int(float(st["step"]))
+
+    def save_checkpoint(self, path, epoch=0, best_val_loss=float("inf")):
+        ck = dict(epoch=epoch, global_step=self.global_step, best_val_loss=best_val_loss,
+                  model_state_dict={k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                  optimizer_state_dict=self.optimizer_state_dict(), scaler_state_dict=self.scaler.state_dict(),
+                  config=dict(self.model.config(), dropout=0.0, drop_path_rate=0.0))
+        torch.save(ck, path)
+        return ck

@@ -1,0 +1,171 @@
+"""Training-step parity on the GPU: the HIP forward+backward+AdamW behind `jatsr_amd.Trainer`
+vs the committed goldens that `oracle/gen_golden_train.py` produced by running the REFERENCE model under torch
+autograd in fp64 (loss, every parameter gradient, the clip norm, the parameter deltas of one AdamW step).
+
+Tolerances.  GEMM / attention operands are bf16 in both directions (what the reference's bf16 autocast does,
+train_ddp_v3m2.py:545), accumulation and everything element-wise is fp32.  A gradient tensor therefore carries a
+relative error of order 2^-8 per bf16 rounding on its path; per-tensor rel-L2 against the fp64 reference is gated at
+GRAD_TOL, and the global quantities (loss, gradient norm) much tighter.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import jatsr_amd._lib as L  # noqa: E402
+import jatsr_amd.recipe as recipe  # noqa: E402
+from helpers import load_golden, rel_l2  # noqa: E402
+from jatsr_amd.model import JaT_AudioSR_V2, JaT_AudioSR_V3  # noqa: E402
+from jatsr_amd.train import Trainer  # noqa: E402
+
+GRAD_TOL = 4e-2        # per-tensor rel-L2 of a gradient vs the fp64 reference
+GRAD_TOL_SMALL = 8e-2  # tensors whose gradient norm is < 1e-3 of the global norm (dominated by rounding noise)
+LOSS_TOL, GNORM_TOL = 2e-3, 1e-2
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def gsub(a, meta):
+    """The subsample rule of oracle/gen_golden_train.py `sub`."""
+    s = meta["strides"]
+    a = np.asarray(a)
+    if a.size <= meta["full_limit"] or a.ndim != 2:
+        return a if a.size <= meta["full_limit"] else a.reshape(-1)[::s[0] * s[1]]
+    return a[::s[0], ::s[1]]
+
+
+def make_trainer(meta, **kw):
+    L.require_gpu()
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    cls = JaT_AudioSR_V3 if meta["norm"] == "rms" else JaT_AudioSR_V2
+    m = cls(**cfg, dropout=0.0, drop_path_rate=0.0)
+    sd = {k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg, meta["norm"], meta["salt"]).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(".rope." in k for k in missing)
+    m = m.to("cuda")
+    tr = Trainer(m, batch_size=meta["B"], frames=meta["T"], lr=meta["lr"], weight_decay=meta["wd"],
+                 grad_clip=meta["clip"], **kw)
+    return m, tr
+
+
+def step_inputs(meta):
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    C, B, T, salt = cfg["input_channels"], meta["B"], meta["T"], meta["salt"]
+    hr = recipe.gaussian("train_hr", (B, C, T), salt + 300)
+    lr = recipe.gaussian("train_lr", (B, C, T), salt + 301)
+    noise = recipe.gaussian("train_noise", (B, C, T), salt + 302)
+    return cuda(hr), cuda(lr), cuda(noise), cuda(np.asarray(meta["t"], np.float32)), torch.tensor(meta["mask"])
+
+
+CASES = ["train_micro_T24", "train_micro_T22_pad", "train_micro_ln_T24", "train_tiny_T128", "train_tiny_T1378"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_step_vs_reference_golden(name):
+    z, meta = load_golden(name)
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    assert [k for k, _ in m.named_parameters()] == meta["names"]   # same tensors, same order as the reference
+    hr, lr, noise, t, mask = step_inputs(meta)
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    # data preparation is exact fp32 arithmetic
+    tv = t.view(-1, 1, 1)
+    assert torch.equal(z_t, tv * hr + (1 - tv) * noise)
+    assert torch.equal(cond, lr * (~mask.to("cuda")).float().view(-1, 1, 1))
+    pred = tr.forward_backward(z_t, t2, cond, hr, want_pred=True)
+    torch.cuda.synchronize()
+    loss = float(tr._scal[0])
+    assert abs(loss - float(z["loss64"])) <= LOSS_TOL * float(z["loss64"]), (loss, float(z["loss64"]))
+    assert abs(float(pred.double().norm()) - float(z["pred_l2"])) <= 1e-2 * float(z["pred_l2"])
+    gn_ref = float(z["gnorm64"])
+    worst, sq = ("", 0.0), 0.0
+    for k in meta["names"]:
+        g = tr.grad(k).detach().cpu().numpy()
+        assert np.isfinite(g).all(), k
+        sq += float((g.astype(np.float64) ** 2).sum())
+        ref_l2 = float(z["gl2_" + k])
+        r = rel_l2(gsub(g, meta), z["g_" + k])
+        n = float(np.linalg.norm(g.astype(np.float64)))
+        tol = GRAD_TOL if ref_l2 >= 1e-3 * gn_ref else GRAD_TOL_SMALL
+        if r / tol > worst[1]:
+            worst = (k, r / tol)
+        assert r <= tol, f"{k}: grad rel-L2 {r:.3e} (ref norm {ref_l2:.3e})"
+        assert abs(n - ref_l2) <= tol * max(ref_l2, 1e-12), f"{k}: grad norm {n:.4e} vs {ref_l2:.4e}"
+    gnorm = sq ** 0.5
+    print(f"{name}: loss {loss:.6f} (ref {float(z['loss64']):.6f}) gnorm {gnorm:.5f} (ref {gn_ref:.5f}) "
+          f"worst tensor {worst[0]} at {worst[1]:.2f} of its tolerance")
+    assert abs(gnorm - gn_ref) <= GNORM_TOL * gn_ref
+    # ---- clip + AdamW: parameter deltas of the first step (|delta| ~ lr for every element: sign-dominated) ----------
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    loss2, gnorm2 = tr.optimizer_step(lr=meta["lr"])
+    assert abs(loss2 - loss) < 1e-7 and abs(gnorm2 - gnorm) <= 1e-4 * gnorm
+    bad = 0.0
+    for k, p in m.named_parameters():
+        d = (p.detach() - before[k]).cpu().numpy()
+        ref = z["d_" + k]
+        ds = gsub(d, meta)
+        # first AdamW step: delta = -lr*(wd*p + g/(|g| + eps*sqrt(1-b2)))  ->  compare where the reference gradient is
+        # not itself at the rounding floor (|g| tiny flips the sign term)
+        gref = np.abs(z["g_" + k]) * min(1.0, meta["clip"] / (gn_ref + 1e-6))
+        sel = gref > max(1e-6, 0.25 * float(np.sqrt((gref.astype(np.float64) ** 2).mean())))
+        if sel.sum() == 0:
+            continue
+        err = np.abs(ds[sel] - ref[sel]).max()
+        bad = max(bad, err / meta["lr"])
+        assert err <= 0.25 * meta["lr"], f"{k}: AdamW delta off by {err:.3e} (lr {meta['lr']})"
+    print(f"{name}: max AdamW delta error {bad:.3f} lr")
+    # the model now computes with the updated weights (bf16 copies re-packed)
+    out_after = m(z_t, t2, cond)
+    assert torch.isfinite(out_after).all() and not torch.equal(out_after, pred)
+
+
+def test_step_is_deterministic_and_loss_scale_invariant():
+    z, meta = load_golden("train_micro_T22_pad")
+    hr, lr, noise, t, mask = step_inputs(meta)
+    grads = []
+    for scale in (1.0, 1.0, 1024.0):
+        m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+        tr.scaler.scale = scale
+        z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+        tr.forward_backward(z_t, t2, cond, hr)
+        grads.append(tr.grads.clone() / scale)
+    assert torch.equal(grads[0], grads[1])                       # fixed-order reductions: bit-reproducible
+    assert rel_l2(grads[2].cpu().numpy(), grads[0].cpu().numpy()) < 5e-3   # power-of-two loss scale: bf16 noise only
+
+
+def test_non_finite_gradients_skip_the_update():
+    z, meta = load_golden("train_micro_T24")
+    m, tr = make_trainer(meta, use_grad_scaler=True, condition_noise_ratio=0.0)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    tr.forward_backward(z_t, t2, cond, hr)
+    tr.grads[5] = float("inf")
+    before = tr.params.clone()
+    s0 = tr.scaler.scale
+    loss, gnorm = tr.optimizer_step(lr=1e-3)
+    assert not np.isfinite(gnorm) and torch.equal(tr.params, before) and tr.scaler.scale == s0 * 0.5
+    assert tr.global_step == 0
+
+
+def test_cond_noise_and_training_loop_reduce_loss():
+    """A few full steps from raw latents (normalisation, cond noise with the adaptive std, CFG dropout, U-shaped t):
+    the loss on a fixed batch goes down, and the adaptive noise scale is ratio * clamp(std(lr_norm), 0.5, 2)."""
+    z, meta = load_golden("train_micro_T24")
+    m, tr = make_trainer(meta, use_grad_scaler=True, seed=7)
+    tr.base_lr, tr.warmup_steps, tr.total_steps = 2e-3, 0, None
+    hr, lr, noise, t, mask = step_inputs(meta)
+    C = hr.shape[1]
+    mean, std = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    cn = torch.randn_like(lr)
+    z_t, t2, cond = tr.prepare(hr, 3.0 * lr, noise=noise, cond_noise=cn, cfg_mask=torch.tensor([False, False]), t=t)
+    expect = 3.0 * lr + cn * (tr.condition_noise_ratio * float((3.0 * lr).std().clamp(0.5, 2.0)))
+    assert torch.allclose(cond, expect, rtol=1e-5, atol=1e-5)
+    losses = [tr.train_step(hr, lr, mean, std, mean, std)["loss"] for _ in range(12)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    assert tr.global_step == 12
+    ck = tr.optimizer_state_dict()
+    assert len(ck["state"]) == len(meta["names"]) and float(ck["state"][0]["step"]) == 12.0
