@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long", action="store_true", help="skip the T=4096 chunked-inference leg (configs[4])")
     ap.add_argument("--eager", action="store_true", help="replay the sampler without the hipGraph (A/B)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (configs[3])")
     args = ap.parse_args()
 
     import numpy as np
@@ -191,6 +192,40 @@ def main():
                               "traffic_note": "bytes/launch = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01/pmc_traffic.json "
                                               "(separate --pmc passes; fabric-side, Infinity-Cache hits included)",
                               "flops_per_launch": g_flops, "avg_launch_ms": g_ms, "launches_timed": n_l.value}
+
+        # ---- training step (BASELINE configs[3]; train_ddp_v3m2.py:533-622): forward + MSE + backward + clip + AdamW on
+        # hr, lr [B,1024,T] with U-shaped t, cond noise and CFG dropout; T=512 for comparability with the headline and
+        # T=1378 (the reference's target_frames).  Runs last: it updates the weights.  FLOPs = 3 x forward closed form.
+        if not args.no_train:
+            from jatsr_amd.train import Trainer
+            del sampler
+            torch.cuda.empty_cache()
+            for blk in model.blocks:
+                blk.dropout_rate = blk.drop_path_rate = 0.0
+            legs = {}
+            mean, std = torch.zeros(C_lat, device=dev), torch.ones(C_lat, device=dev)
+            for Tt in (T, 1378):
+                trainer = Trainer(model, batch_size=B, frames=Tt, seed=1)
+                hr_t = torch.from_numpy(recipe.gaussian("train_hr", (B, C_lat, Tt), 300)).to(dev)
+                lr_t = torch.from_numpy(recipe.gaussian("train_lr", (B, C_lat, Tt), 301)).to(dev)
+                for _ in range(2):
+                    st = trainer.train_step(hr_t, lr_t, mean, std, mean, std)
+                torch.cuda.synchronize()
+                ts0 = time.perf_counter()
+                nt = 5
+                for _ in range(nt):
+                    st = trainer.train_step(hr_t, lr_t, mean, std, mean, std)
+                torch.cuda.synchronize()
+                ts = (time.perf_counter() - ts0) / nt
+                assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"])
+                tfl = 3 * recipe.forward_flops(cfg, B, Tt) / ts / 1e12
+                legs[f"T{Tt}"] = {"ms_per_step": ts * 1e3, "latent_frames_per_s": B * Tt / ts, "tflops": tfl,
+                                  "mfma_frac": tfl / PEAK_BF16_TFLOPS, "loss": st["loss"], "grad_norm": st["grad_norm"],
+                                  "workspace_GB": trainer.workspace_bytes() / 1e9}
+                del trainer, hr_t, lr_t
+                torch.cuda.empty_cache()
+            result["train_step"] = {"workload": f"{args.config} bf16 training step B={B}/GPU (fwd + MSE + bwd + "
+                                                "clip_grad_norm 1.0 + AdamW), dropout=drop_path=0, one GPU", **legs}
 
         # ---- CPU baseline: numpy oracle (port of the reference fp32 CPU forward) on a bounded sample --------
         if world == 1 and not args.no_cpu_baseline:

@@ -259,6 +259,7 @@ int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipSt
     HIPCHK(hipStreamSynchronize(s));
   }
   if (build_tables) HIPCHK(hipStreamSynchronize(s));
+  m->group_copy_stale = false;
   m->loaded = true;
   return JAT_OK;
 }
@@ -372,7 +373,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
   // one block per (sample, KV group): worth it only when B * Hkv blocks fill the 256 CUs (measured: +1.8 % at
   // B = 56, -5 % at B = 28); fuse_env = 2 forces it (tests)
-  const bool fused_attn = fuse_env && L.wqkv_g && ntok == 128 && !f && (B * m->Hkv >= 192 || fuse_env == 2);
+  const bool fused_attn = fuse_env && L.wqkv_g && !m->group_copy_stale && ntok == 128 && !f && (B * m->Hkv >= 192 || fuse_env == 2);
   if (fused_attn) {
     // q/k/v projection + RoPE + attention of one (sample, KV group) per block: q, k, v stay in LDS
     GemmArgs a{};

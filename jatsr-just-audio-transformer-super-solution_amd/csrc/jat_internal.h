@@ -50,6 +50,8 @@ struct jat_model {
   // GEMM tile/pipeline variant per call site: qkv, out_proj, fc1, fc2, everything else (gemm.hip table)
   int variants[5] = {-1, -1, -1, -1, -1};  // -1: choose by shape (pick_variant)
   mutable int last_fold_np = 0;            // partial-sum slots per row written by the latest folding producer
+  bool group_copy_stale = false;           // the training re-pack skips wqkv_g: the fused QKV+attention kernel is off until
+                                           // the next full jat_model_load_weights
 };
 enum { G_QKV = 0, G_OUT = 1, G_FC1 = 2, G_FC2 = 3, G_OTHER = 4 };
 

@@ -125,8 +125,8 @@ int train_red_blocks();         // blocks (= partial sums) of the scalar reducti
 hipError_t launch_gate_bwd(const float* dx, const bf16_t* y, const float* gate, int64_t gate_bstride, bf16_t* dy,
                            float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, hipStream_t s);
 hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, const float* scale, int64_t mod_bstride,
-                           float* dx, int accumulate, float* part, float* dshift, float* dscale, int64_t dmod_bstride,
-                           float* dw, int B, int D, int ntok, int mode, hipStream_t s);
+                           float* dx, int accumulate, float* part, float* dw_part, float* dshift, float* dscale,
+                           int64_t dmod_bstride, float* dw, int B, int D, int ntok, int mode, hipStream_t s);
 hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
                                 const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
                                 int B, int N, int Hq, int Hkv, int npad, hipStream_t s);
@@ -137,8 +137,12 @@ hipError_t launch_adamw(float* p, float* g, float* m, float* v, int64_t n, const
                         float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
 hipError_t launch_small_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dW, float* db, int B, int N,
                            int K, int silu_x, hipStream_t s);
-hipError_t launch_small_dx(const float* dy, int64_t ldy, const float* W, float* part, float* dx, int B, int N, int K,
-                           int accumulate, const float* silu_pre, hipStream_t s);
+int small_dx_slab(int N);   // rows of W per partial-sum slab
+hipError_t launch_small_dx(const float* dy, int64_t ldy, const void* W, int w_is_bf16, float* part, float* dx, int B, int N,
+                           int K, int accumulate, const float* silu_pre, hipStream_t s);
+// n independent fp32 copies described by a device table of (src, dst, count) triples, one launch
+struct CopyJob { const float* src; float* dst; int64_t n; };
+hipError_t launch_multi_copy(const CopyJob* jobs_dev, int njobs, hipStream_t s);
 hipError_t launch_silu_f32(const float* in, float* out, int64_t n, hipStream_t s);
 hipError_t launch_unpack_qkv_grad(const float* fused, float* gq, float* gk, float* gv, int D, int kvD, int K, hipStream_t s);
 hipError_t launch_flow_mix(const float* x, const float* noise, const float* t, float* z, int B, int64_t per_sample, hipStream_t s);

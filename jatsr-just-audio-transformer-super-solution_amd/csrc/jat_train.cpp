@@ -48,13 +48,15 @@ struct jat_trainer {
   bf16_t *dy, *dh, *dxn, *dao, *dqkv, *tA, *tB, *dyf;
   int64_t o_pe_w1, o_pe_b1, o_pe_w2, o_pe_b2, o_te_w1, o_te_b1, o_te_w2, o_te_b2, o_fn, o_wf, o_bf;
   bool rms = true;
+  CopyJob* copy_jobs = nullptr;        // device table: fp32 master slices -> the model's fp32 operand tensors
+  int n_copy_jobs = 0;
+  float* dw_part = nullptr;
 };
 
 namespace {
 
-int repack(jat_trainer* tr, hipStream_t s) {
+int build_transposes(jat_trainer* tr, hipStream_t s) {
   jat_model* m = tr->m;
-  JCHK(jat_pack_weights(m, tr->prefs.data(), (int32_t)tr->prefs.size(), s, false));
   const int D = m->D, Nqkv = D + 2 * m->kvD;
   for (int l = 0; l < m->depth; ++l) {
     const LayerW& W = m->layers[l];
@@ -67,6 +69,32 @@ int repack(jat_trainer* tr, hipStream_t s) {
   KCHK(launch_transpose_bf16(m->pe_w2, m->bott, D, m->bott, tr->pe_w2T, D, s));
   KCHK(launch_transpose_bf16(m->wfinal, D, m->Fout, D, tr->wfinalT, m->Fout, s));
   return JAT_OK;
+}
+
+// After an optimiser step: fp32 master -> the operand copies the kernels read.  No host synchronisation; the small
+// fp32 tensors go in one table-driven launch, the GEMM weights in one cast per matrix, then the transposed copies.
+// The group-major QKV copy of the fused inference kernel is NOT rebuilt (m->group_copy_stale).
+int repack(jat_trainer* tr, hipStream_t s) {
+  jat_model* m = tr->m;
+  const float* P = tr->P;
+  const int D = m->D, kvD = m->kvD, mlp = m->mlp;
+  m->group_copy_stale = true;
+  KCHK(launch_multi_copy(tr->copy_jobs, tr->n_copy_jobs, s));
+  KCHK(launch_cast_bf16(P + tr->o_pe_w1, m->pe_w1, (int64_t)m->bott * m->Kp, s));
+  KCHK(launch_cast_bf16(P + tr->o_pe_w2, m->pe_w2, (int64_t)D * m->bott, s));
+  KCHK(launch_cast_bf16(P + tr->o_wf, m->wfinal, (int64_t)m->Fout * D, s));
+  for (int l = 0; l < m->depth; ++l) {
+    const LayerW& W = m->layers[l];
+    const TLayer& L = tr->L[l];
+    KCHK(launch_cast_bf16_rope_rows(P + L.o_q, W.wqkv, D, D, s));
+    KCHK(launch_cast_bf16_rope_rows(P + L.o_k, W.wqkv + (int64_t)D * D, kvD, D, s));
+    KCHK(launch_cast_bf16(P + L.o_v, W.wqkv + (int64_t)(D + kvD) * D, (int64_t)kvD * D, s));
+    KCHK(launch_cast_bf16(P + L.o_o, W.wo, (int64_t)D * D, s));
+    KCHK(launch_cast_bf16(P + L.o_w1, W.w1, (int64_t)mlp * D, s));
+    KCHK(launch_cast_bf16(P + L.o_w2, W.w2, (int64_t)D * mlp, s));
+    KCHK(launch_cast_bf16(P + L.o_ada_w, m->wada + (int64_t)l * 6 * D * D, (int64_t)6 * D * D, s));
+  }
+  return build_transposes(tr, s);
 }
 
 // dW[out,in] = dY^T X and (optionally) db[out] = column sums of dY, from dY bf16 [M,out] and X bf16 [M,in]
@@ -167,7 +195,7 @@ int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipSt
   KCHK(launch_patchify(tr->dpred, nullptr, tr->dyf, B, B, B, m->Cin, 0, T, ntok, s));
   JCHK(input_grad(tr, tr->dyf, m->Fout, tr->wfinalT, D, tr->dxn, s));
   JCHK(weight_grad(tr, tr->dyf, m->Fout, tr->xnf, D, G + tr->o_wf, G + tr->o_bf, s));
-  KCHK(launch_norm_bwd(tr->x[m->depth], tr->dxn, m->final_norm, nullptr, 0, tr->dx, 0, tr->part, nullptr, nullptr, 0,
+  KCHK(launch_norm_bwd(tr->x[m->depth], tr->dxn, m->final_norm, nullptr, 0, tr->dx, 0, tr->part, tr->dw_part, nullptr, nullptr, 0,
                        tr->rms ? G + tr->o_fn : nullptr, B, D, ntok, mode, s));
   for (int l = m->depth - 1; l >= 0; --l) {
     TLayer& L = tr->L[l];
@@ -180,7 +208,7 @@ int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipSt
     KCHK(launch_gelu_bwd(L.h_pre, tr->dh, (int64_t)M * m->mlp, s));
     JCHK(input_grad(tr, tr->dh, m->mlp, L.w1T, D, tr->dxn, s));
     JCHK(weight_grad(tr, tr->dh, m->mlp, L.xn2, D, G + L.o_w1, G + L.o_b1, s));
-    KCHK(launch_norm_bwd(L.x_mid, tr->dxn, m->layers[l].norm2, mod + 4 * D, mstride, tr->dx, 1, tr->part, dmod + 3 * D,
+    KCHK(launch_norm_bwd(L.x_mid, tr->dxn, m->layers[l].norm2, mod + 4 * D, mstride, tr->dx, 1, tr->part, tr->dw_part, dmod + 3 * D,
                          dmod + 4 * D, mstride, tr->rms ? G + L.o_n2 : nullptr, B, D, ntok, mode, s));
     // x_mid = x_in + gate_msa * out_proj(attn(norm1(x_in) * (1 + scale_msa) + shift_msa))   :297-300
     KCHK(launch_gate_bwd(tr->dx, L.y_attn, mod + 2 * D, mstride, tr->dy, tr->part, dmod + 2 * D, mstride, B, D, ntok, s));
@@ -191,7 +219,7 @@ int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipSt
     JCHK(input_grad(tr, tr->dqkv, Nqkv, L.wqkvT, D, tr->dxn, s));
     JCHK(weight_grad(tr, tr->dqkv, Nqkv, L.xn1, D, tr->dwqkv, nullptr, s));
     KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, s));
-    KCHK(launch_norm_bwd(tr->x[l], tr->dxn, m->layers[l].norm1, mod + 1 * D, mstride, tr->dx, 1, tr->part, dmod + 0 * D,
+    KCHK(launch_norm_bwd(tr->x[l], tr->dxn, m->layers[l].norm1, mod + 1 * D, mstride, tr->dx, 1, tr->part, tr->dw_part, dmod + 0 * D,
                          dmod + 1 * D, mstride, tr->rms ? G + L.o_n1 : nullptr, B, D, ntok, mode, s));
   }
   // patch embed: Linear(Kp -> bott) - GELU - Linear(bott -> D)   (jat_audiosr_v3.py:221-225); no gradient to the input
@@ -203,13 +231,12 @@ int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipSt
   // adaLN modulation Linear(SiLU(t_emb)) of every block (:275-278), then the t_embedder MLP (:364-369); fp32, B rows
   for (int l = 0; l < m->depth; ++l) {
     TLayer& L = tr->L[l];
-    const float* dmod = tr->dmod + (int64_t)l * 6 * D;
-    KCHK(launch_small_dw(dmod, mstride, tr->t_emb, D, G + L.o_ada_w, G + L.o_ada_b, B, 6 * D, D, 1, s));
-    KCHK(launch_small_dx(dmod, mstride, tr->P + L.o_ada_w, tr->small_part, tr->dt_emb, B, 6 * D, D, l > 0,
-                         l == m->depth - 1 ? tr->t_emb : nullptr, s));
+    KCHK(launch_small_dw(tr->dmod + (int64_t)l * 6 * D, mstride, tr->t_emb, D, G + L.o_ada_w, G + L.o_ada_b, B, 6 * D, D, 1, s));
   }
+  // d silu(t_emb) = dmod [B, depth*6D] @ W_ada (the packed bf16 copy the forward multiplied with), all layers at once
+  KCHK(launch_small_dx(tr->dmod, mstride, m->wada, 1, tr->small_part, tr->dt_emb, B, (int)mstride, D, 0, tr->t_emb, s));
   KCHK(launch_small_dw(tr->dt_emb, D, tr->t_h, D, G + tr->o_te_w2, G + tr->o_te_b2, B, D, D, 0, s));
-  KCHK(launch_small_dx(tr->dt_emb, D, tr->P + tr->o_te_w2, tr->small_part, tr->du1, B, D, D, 0, tr->u1, s));
+  KCHK(launch_small_dx(tr->dt_emb, D, tr->P + tr->o_te_w2, 0, tr->small_part, tr->du1, B, D, D, 0, tr->u1, s));
   KCHK(launch_small_dw(tr->du1, D, tr->e_sin, D, G + tr->o_te_w1, G + tr->o_te_b1, B, D, D, 0, s));
   return JAT_OK;
 }
@@ -322,7 +349,13 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     tr->dwqkv = (float*)take((size_t)Nqkv * D * 4);
     tr->dsilu = (float*)take((size_t)B * D * 4); tr->dt_emb = (float*)take((size_t)B * D * 4);
     tr->du1 = (float*)take((size_t)B * D * 4);
-    tr->small_part = (float*)take((size_t)((6 * D + 63) / 64) * B * D * 4);
+    {
+      const int Nall = depth * 6 * D;
+      const size_t slabs = std::max((Nall + small_dx_slab(Nall) - 1) / small_dx_slab(Nall), (D + small_dx_slab(D) - 1) / small_dx_slab(D));
+      tr->small_part = (float*)take(slabs * B * D * 4);
+    }
+    tr->dw_part = (float*)take((size_t)B * D * 4);
+    tr->copy_jobs = (CopyJob*)take((size_t)(8 + 5 * depth + 2) * sizeof(CopyJob));
     tr->dy = (bf16_t*)take(MD2); tr->dh = (bf16_t*)take((size_t)M * std::max(mlp, bott) * 2);
     tr->dxn = (bf16_t*)take(MD2); tr->dao = (bf16_t*)take(MD2); tr->dqkv = (bf16_t*)take((size_t)M * Nqkv * 2);
     tr->dyf = (bf16_t*)take((size_t)M * m->Fout * 2);
@@ -339,7 +372,28 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
       if (hipMemsetAsync(tr->blob, 0, o, s) != hipSuccess) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "memset failed"); }
     }
   }
-  rc = repack(tr, s);
+  {
+    std::vector<CopyJob> jobs;
+    auto job = [&](int64_t o, float* dst, int64_t cnt) { jobs.push_back(CopyJob{params_flat + o, dst, cnt}); };
+    job(tr->o_pe_b1, m->pe_b1, bott); job(tr->o_pe_b2, m->pe_b2, D);
+    job(tr->o_te_w1, m->te_w1, (int64_t)D * D); job(tr->o_te_b1, m->te_b1, D);
+    job(tr->o_te_w2, m->te_w2, (int64_t)D * D); job(tr->o_te_b2, m->te_b2, D);
+    job(tr->o_bf, m->bfinal, m->Fout);
+    if (tr->rms) job(tr->o_fn, m->final_norm, D);
+    for (int l = 0; l < depth; ++l) {
+      const TLayer& L = tr->L[l];
+      if (tr->rms) { job(L.o_n1, m->layers[l].norm1, D); job(L.o_n2, m->layers[l].norm2, D); }
+      job(L.o_b1, m->layers[l].b1, mlp); job(L.o_b2, m->layers[l].b2, D);
+      job(L.o_ada_b, m->bada + (int64_t)l * 6 * D, (int64_t)6 * D);
+    }
+    tr->n_copy_jobs = (int)jobs.size();
+    if (hipMemcpyAsync(tr->copy_jobs, jobs.data(), jobs.size() * sizeof(CopyJob), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      jat_trainer_destroy(tr);
+      return fail(JAT_E_HIP, "copy-table upload failed");
+    }
+  }
+  rc = build_transposes(tr, s);   // the model's own copies were packed from these very tensors by jat_model_load_weights
   if (rc != JAT_OK) { jat_trainer_destroy(tr); return rc; }
   if (hipStreamSynchronize(s) != hipSuccess) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "trainer setup failed"); }
   *out = tr;

@@ -306,10 +306,22 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < 3 * D; i += 256)
     po[i] = red[i] + red[3 * D + i] + red[6 * D + i] + red[9 * D + i];
 }
-// dshift/dscale: [B] rows with stride dmod_bstride (nullptr: skip); dw [D] (nullptr: skip).  part: B*nchunk*3*D floats.
+// which = blockIdx.z: 0 -> dshift[b], 1 -> dscale[b], 2 -> dw_part[b]  (each the sum over the token chunks of sample b)
+__global__ void __launch_bounds__(256) norm_bwd_finish_kernel(const float* __restrict__ part, int nchunk, int D,
+                                                              float* __restrict__ dshift, float* __restrict__ dscale,
+                                                              int64_t dmod_bstride, float* __restrict__ dw_part) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, which = blockIdx.z;
+  float* out = which == 0 ? dshift : (which == 1 ? dscale : dw_part);
+  if (c >= D || !out) return;
+  float acc = 0.f;
+  for (int k = 0; k < nchunk; ++k) acc += part[(((int64_t)b * nchunk + k) * 3 + which) * D + c];
+  out[(int64_t)b * (which == 2 ? (int64_t)D : dmod_bstride) + c] = acc;
+}
+// dshift/dscale: [B] rows with stride dmod_bstride (nullptr: skip); dw [D] (nullptr: skip).  part: B*nchunk*3*D floats,
+// dw_part: B*D floats.
 hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, const float* scale, int64_t mod_bstride,
-                           float* dx, int accumulate, float* part, float* dshift, float* dscale, int64_t dmod_bstride,
-                           float* dw, int B, int D, int ntok, int mode, hipStream_t s) {
+                           float* dx, int accumulate, float* part, float* dw_part, float* dshift, float* dscale,
+                           int64_t dmod_bstride, float* dw, int B, int D, int ntok, int mode, hipStream_t s) {
   if (D % 256 != 0 || D > 2048) return hipErrorInvalidValue;
   const int nchunk = train_nchunk(ntok);
 #define NORM_BWD_CASE(NCH)                                                                                              \
@@ -326,14 +338,12 @@ hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, con
     NORM_BWD_CASE(8)
   }
 #undef NORM_BWD_CASE
-  const dim3 g((D + 255) / 256, B);
-  if (dshift)
-    hipLaunchKernelGGL(reduce_chunks_kernel, g, dim3(256), 0, s, part, nchunk, (int64_t)3 * D, dshift, dmod_bstride, B, D, 0);
-  if (dscale)
-    hipLaunchKernelGGL(reduce_chunks_kernel, g, dim3(256), 0, s, part + D, nchunk, (int64_t)3 * D, dscale, dmod_bstride, B, D, 0);
+  // one launch finishes dshift / dscale per sample and the per-sample part of dw; a second sums dw over the samples
+  hipLaunchKernelGGL(norm_bwd_finish_kernel, dim3((D + 255) / 256, B, 3), dim3(256), 0, s, part, nchunk, D, dshift, dscale,
+                     dmod_bstride, dw ? dw_part : nullptr);
   if (dw)
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part + 2 * D, nchunk, (int64_t)3 * D, dw,
-                       (int64_t)0, B, D, 1);
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dw_part, 1, (int64_t)D, dw, (int64_t)0, B,
+                       D, 1);
   return hipGetLastError();
 }
 
@@ -679,45 +689,81 @@ hipError_t launch_adamw(float* p, float* g, float* m, float* v, int64_t n, const
   return hipGetLastError();
 }
 
-// ---- small-batch fp32 Linear backward (adaLN modulation and t_embedder: at most a few dozen rows) ----------------------
+// ---- small-batch Linear backward (adaLN modulation and t_embedder: B <= 32 rows, weights up to [215040, 1280]) --------
+// Both are HBM-bound streams over the weight-sized operand: dW is written once (fp32), W is read once (bf16 or fp32).
 // dW[n][k] = sum_b dy[b][n] * x[b][k]   (optionally x -> silu(x));   db[n] = sum_b dy[b][n]
+// One block = DW_R output rows; a thread owns 4 consecutive k (float4 stores) and keeps DW_R x 4 accumulators.
+constexpr int DW_R = 16;
 __global__ void __launch_bounds__(256) small_dw_kernel(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ dW, float* __restrict__ db, int B,
                                                        int N, int K, int silu_x) {
-  const int n = blockIdx.x;
-  float bsum = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float acc = 0.f;
+  const int n0 = blockIdx.x * DW_R;
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    f32x4_t acc[DW_R];
+#pragma unroll
+    for (int r = 0; r < DW_R; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < B; ++b) {
-      float xv = x[(int64_t)b * ldx + k];
-      if (silu_x) xv = xv / (1.0f + __expf(-xv));
-      acc += dy[(int64_t)b * ldy + n] * xv;
+      f32x4_t xv = *(const f32x4_t*)(x + (int64_t)b * ldx + k);
+      if (silu_x) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xv[j] / (1.0f + __expf(-xv[j]));
+      }
+#pragma unroll
+      for (int r = 0; r < DW_R; ++r) {
+        const float d = (n0 + r < N) ? dy[(int64_t)b * ldy + n0 + r] : 0.f;   // uniform across the block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] += d * xv[j];
+      }
     }
-    dW[(int64_t)n * K + k] = acc;
+#pragma unroll
+    for (int r = 0; r < DW_R; ++r)
+      if (n0 + r < N) *(f32x4_t*)(dW + (int64_t)(n0 + r) * K + k) = acc[r];
   }
-  if (db && threadIdx.x == 0) {
-    for (int b = 0; b < B; ++b) bsum += dy[(int64_t)b * ldy + n];
-    db[n] = bsum;
+  if (db && threadIdx.x < DW_R && n0 + threadIdx.x < N) {
+    float bsum = 0.f;
+    for (int b = 0; b < B; ++b) bsum += dy[(int64_t)b * ldy + n0 + threadIdx.x];
+    db[n0 + threadIdx.x] = bsum;
   }
 }
-// partial dx: part[split][b][k] = sum_{n in split} dy[b][n] * W[n][k];  B <= 32 per launch group
-__global__ void __launch_bounds__(256) small_dx_kernel(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ W,
-                                                       float* __restrict__ part, int B, int N, int K, int rows_per_split) {
-  const int k = blockIdx.x * 256 + threadIdx.x, split = blockIdx.y;
-  if (k >= K) return;
-  const int n0 = split * rows_per_split, n1 = min(n0 + rows_per_split, N);
-  float acc[32];
+// partial dx: part[slab][b][k] = sum_{n in slab} dy[b][n] * W[n][k]; W bf16 (packed operand copy) or fp32.
+// The slab's dy values sit in LDS as [n][32 b]; a thread owns 4 consecutive k and 32 x 4 accumulators (B <= 32).
+template <typename WT>
+__global__ void __launch_bounds__(320) small_dx_kernel(const float* __restrict__ dy, int64_t ldy, const WT* __restrict__ W,
+                                                       float* __restrict__ part, int B, int N, int K, int slab) {
+  extern __shared__ float sdy[];   // [slab][32]
+  const int n0 = blockIdx.x * slab, n1 = min(n0 + slab, N);
+  for (int i = threadIdx.x; i < slab * 32; i += blockDim.x) {
+    const int n = n0 + (i >> 5), b = i & 31;
+    sdy[i] = (n < N && b < B) ? dy[(int64_t)b * ldy + n] : 0.f;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
+    f32x4_t acc[32];
 #pragma unroll
-  for (int b = 0; b < 32; ++b) acc[b] = 0.f;
-  for (int n = n0; n < n1; ++n) {
-    const float wv = W[(int64_t)n * K + k];
+    for (int b = 0; b < 32; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int n = n0; n < n1; ++n) {
+      f32x4_t w;
+      if constexpr (sizeof(WT) == 2) {
+        const u32x2_t ww = *(const u32x2_t*)(W + (int64_t)n * K + k);
+        w[0] = __builtin_bit_cast(float, ww[0] << 16); w[1] = __builtin_bit_cast(float, ww[0] & 0xffff0000u);
+        w[2] = __builtin_bit_cast(float, ww[1] << 16); w[3] = __builtin_bit_cast(float, ww[1] & 0xffff0000u);
+      } else {
+        w = *(const f32x4_t*)(W + (int64_t)n * K + k);
+      }
+      const f32x4_t* row = (const f32x4_t*)(sdy + (n - n0) * 32);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4_t d = row[q];   // broadcast read: every lane the same address
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[q * 4 + e][j] += d[e] * w[j];
+      }
+    }
 #pragma unroll
     for (int b = 0; b < 32; ++b)
-      if (b < B) acc[b] += dy[(int64_t)b * ldy + n] * wv;
+      if (b < B) *(f32x4_t*)(part + ((int64_t)blockIdx.x * B + b) * K + k) = acc[b];
   }
-#pragma unroll
-  for (int b = 0; b < 32; ++b)
-    if (b < B) part[((int64_t)split * B + b) * K + k] = acc[b];
 }
 // dx[b][k] (+)= sum_split part[split][b][k], optionally times silu'(pre[b][k])
 __global__ void __launch_bounds__(256) small_dx_finish_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ dx,
@@ -735,15 +781,23 @@ __global__ void __launch_bounds__(256) small_dx_finish_kernel(const float* __res
 }
 hipError_t launch_small_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dW, float* db, int B, int N,
                            int K, int silu_x, hipStream_t s) {
-  hipLaunchKernelGGL(small_dw_kernel, dim3(N), dim3(256), 0, s, dy, ldy, x, ldx, dW, db, B, N, K, silu_x);
+  if (K % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(small_dw_kernel, dim3((N + DW_R - 1) / DW_R), dim3(256), 0, s, dy, ldy, x, ldx, dW, db, B, N, K, silu_x);
   return hipGetLastError();
 }
-// part must hold nsplit * B * K floats with nsplit = ceil(N / 64)
-hipError_t launch_small_dx(const float* dy, int64_t ldy, const float* W, float* part, float* dx, int B, int N, int K,
-                           int accumulate, const float* silu_pre, hipStream_t s) {
-  if (B > 32) return hipErrorInvalidValue;
-  const int rows = 64, nsplit = (N + rows - 1) / rows;
-  hipLaunchKernelGGL(small_dx_kernel, dim3((K + 255) / 256, nsplit), dim3(256), 0, s, dy, ldy, W, part, B, N, K, rows);
+int small_dx_slab(int N) { return N >= 16384 ? 256 : 32; }
+// part must hold ceil(N / small_dx_slab(N)) * B * K floats.  w_is_bf16: W is the packed bf16 operand copy.
+hipError_t launch_small_dx(const float* dy, int64_t ldy, const void* W, int w_is_bf16, float* part, float* dx, int B, int N,
+                           int K, int accumulate, const float* silu_pre, hipStream_t s) {
+  if (B > 32 || K % 4 != 0) return hipErrorInvalidValue;
+  const int slab = small_dx_slab(N), nsplit = (N + slab - 1) / slab;
+  const int threads = K / 4 >= 320 ? 320 : 64 * ((K / 4 + 63) / 64);
+  if (w_is_bf16)
+    hipLaunchKernelGGL(small_dx_kernel<bf16_t>, dim3(nsplit), dim3(threads), (size_t)slab * 32 * 4, s, dy, ldy, (const bf16_t*)W,
+                       part, B, N, K, slab);
+  else
+    hipLaunchKernelGGL(small_dx_kernel<float>, dim3(nsplit), dim3(threads), (size_t)slab * 32 * 4, s, dy, ldy, (const float*)W,
+                       part, B, N, K, slab);
   const int64_t BK = (int64_t)B * K;
   hipLaunchKernelGGL(small_dx_finish_kernel, dim3((unsigned)((BK + 255) / 256)), dim3(256), 0, s, part, nsplit, dx, BK,
                      accumulate, silu_pre);
@@ -834,5 +888,20 @@ hipError_t launch_tensor_std(const float* x, int64_t n, float* part, float* mean
   hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f / (float)n, mean2);
   hipLaunchKernelGGL(moment_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, x, n, (const float*)mean2, part);
   hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f / (float)(n - 1), out2);
+  return hipGetLastError();
+}
+
+// ---- table-driven copies: the fp32 tensors the kernels read directly (biases, norm weights, t_embedder) go from the
+// flat master buffer to the model's packed blob in ONE launch after every optimiser step ---------------------------------
+__global__ void __launch_bounds__(256) multi_copy_kernel(const CopyJob* __restrict__ jobs) {
+  const CopyJob j = jobs[blockIdx.y];
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < j.n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < j.n) *(f32x4_t*)(j.dst + i) = *(const f32x4_t*)(j.src + i);   // tensors start 16-B aligned on both sides
+    else for (int64_t k = i; k < j.n; ++k) j.dst[k] = j.src[k];
+  }
+}
+hipError_t launch_multi_copy(const CopyJob* jobs_dev, int njobs, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(32, njobs), dim3(256), 0, s, jobs_dev);
   return hipGetLastError();
 }
