@@ -74,7 +74,7 @@ def main():
     B, T, C_lat = args.B, args.T, cfg["input_channels"]
     t0 = time.time()
     sd = recipe.make_state_dict(cfg)
-    model = jatsr_amd.JaT_AudioSR_V3(**cfg)
+    model = jatsr_amd.JaT_AudioSR_V3(**cfg, dropout=0.1, drop_path_rate=0.05)   # training-only rates, train_ddp_v3m2.py:82-83
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     model = model.to(dev).eval()
     lr = torch.from_numpy(recipe.gaussian("lr_latent", (B, C_lat, T), 1234 + 2 * rank)).to(dev)
@@ -200,8 +200,6 @@ def main():
             from jatsr_amd.train import Trainer
             del sampler
             torch.cuda.empty_cache()
-            for blk in model.blocks:
-                blk.dropout_rate = blk.drop_path_rate = 0.0
             legs = {}
             mean, std = torch.zeros(C_lat, device=dev), torch.ones(C_lat, device=dev)
             for Tt in (T, 1378):
@@ -225,7 +223,8 @@ def main():
                 del trainer, hr_t, lr_t
                 torch.cuda.empty_cache()
             result["train_step"] = {"workload": f"{args.config} bf16 training step B={B}/GPU (fwd + MSE + bwd + "
-                                                "clip_grad_norm 1.0 + AdamW), dropout=drop_path=0, one GPU", **legs}
+                                                "clip_grad_norm 1.0 + AdamW), dropout 0.1 / DropPath 0..0.05 "
+                                                "as train_ddp_v3m2.py:82-83, one GPU", **legs}
 
         # ---- CPU baseline: numpy oracle (port of the reference fp32 CPU forward) on a bounded sample --------
         if world == 1 and not args.no_cpu_baseline:

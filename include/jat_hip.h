@@ -121,13 +121,17 @@ int jat_crossfade_pair(const float* prev, int32_t Tp, const float* cur, int32_t 
  * Parameters, gradients and the two AdamW moments are four caller-owned flat fp32 device buffers of `total` floats
  * (total % 4 == 0); `params` names the reference state_dict tensors as 16-byte aligned slices of params_flat, and the
  * gradient / moment of a tensor lives at the same offset of its buffer.  Gaps between tensors must be zero-filled.
- * Dropout / DropPath (jat_audiosr_v3.py:38-64,139,269-271) are not implemented: the step is the reference's with
- * dropout = drop_path_rate = 0.  Per-rank batch B <= 32. */
+ * Dropout (attention probabilities :175, MLP :269,271) and DropPath (:38-64, :300,306) draw their masks from a
+ * counter-based generator keyed by (rng_seed of the step, layer, site, element index) — the same Bernoulli(1-p) / (1-p)
+ * semantics as nn.Dropout / drop_path, a different random stream than torch's Philox.  Per-rank batch B <= 32. */
 typedef struct jat_trainer jat_trainer;
 int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, int32_t n_params, float* params_flat,
                        float* grads_flat, float* exp_avg, float* exp_avg_sq, int64_t total, int32_t B, int32_t T,
                        void* stream, jat_trainer** out);
 void jat_trainer_destroy(jat_trainer* tr);
+/* Per-layer rates (host arrays [depth]): dropout[l] = the block's nn.Dropout p (jat_audiosr_v3.py:262,269,271),
+ * drop_path[l] = linspace(0, drop_path_rate, depth)[l] (:372-377).  Default: all zero. */
+int jat_trainer_set_regularisers(jat_trainer* tr, const float* dropout, const float* drop_path);
 int jat_trainer_workspace_bytes(const jat_trainer* tr, size_t* out);
 /* hr_norm, noise, z_t: [B,C,T]; cond [B,Cc,T] is modified in place: cond = (cond + cond_noise * ratio *
  * (adaptive ? clamp(std(cond), 0.5, 2) : 1)) * keep[b]   (cond_noise / keep may be NULL); t [B]. */
@@ -137,7 +141,7 @@ int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float* cond, cons
 /* Overwrites grads_flat with d(loss * loss_scale)/d(param); loss_out (device, 1 float, nullable) = unscaled loss;
  * x_pred_out (device [B,C,T], nullable) = the prediction. */
 int jat_trainer_fwd_bwd(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond, const float* target,
-                        float loss_scale, float* loss_out, float* x_pred_out, void* stream);
+                        float loss_scale, uint64_t rng_seed, float* loss_out, float* x_pred_out, void* stream);
 /* grad_norm_out (device, 1 float, nullable) = L2 norm of the loss-SCALED gradients (divide by loss_scale).  A
  * non-finite norm leaves parameters and moments untouched (GradScaler.step).  `step` is 1-based (bias correction). */
 int jat_trainer_optim(jat_trainer* tr, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -151,6 +151,16 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
           st[qt][kt][r] = pv;
           sum += pv;
         }
+      if (p.drop.thresh) {   // training: dropout on the normalised probabilities = mask the numerators, keep the row sum
+        const int64_t qrow = (((int64_t)b * p.Hq + h) * N + min(q0 + qt * 16 + frow, N - 1)) * N;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
+            st[qt][kt][r] *= jat_drop_mult(p.drop, (uint64_t)(qrow + key));
+          }
+      }
       l_run[qt] = l_run[qt] * alpha + sum;
       if (kb > 0) {
 #pragma unroll
@@ -361,7 +371,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid((a.N + 64 * QT - 1) / (64 * QT), a.Hq, a.B);
   static const int kvb_env = getenv("JAT_ATTN_KVB") ? atoi(getenv("JAT_ATTN_KVB")) : 64;
   static const int group_env = getenv("JAT_ATTN_GROUP") ? atoi(getenv("JAT_ATTN_GROUP")) : 1;
-  if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse) {   // the sampler's shape: K/V staged once per KV head
+  if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse && !a.drop.thresh) {   // the sampler's shape: K/V staged once per KV head
     hipLaunchKernelGGL((attn_group_kernel<1, 8>), dim3(a.Hkv, a.B), dim3(512), 0, s, a);
   } else if (kvb_env == 64 || a.N <= 64) {
     hipLaunchKernelGGL((attn_fwd_kernel<QT, 64>), grid, dim3(256), 0, s, a);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "jat_rng.h"
+
 typedef uint16_t bf16_t;  // raw bf16 bits
 
 // ---- GEMM: C[M,N] = A[M,K] * W[N,K]^T with a fused epilogue ------------------------------------
@@ -78,6 +80,7 @@ struct AttnArgs {
   int B, N, Hq, Hkv, npad;
   float scale_log2e; // (1/sqrt(64)) * log2(e)
   float* lse;        // optional [B, Hq, N] fp32: log2-domain log-sum-exp per query row (training forward), else nullptr
+  DropSpec drop;     // training: dropout on the attention probabilities (thresh == 0: off); element ((b*Hq+h)*N + q)*N + key
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -116,20 +119,21 @@ hipError_t launch_crossfade_pair(const float* prev, int Tp, const float* cur, in
 // ---- training step (train.hip): backward, loss, optimiser, data preparation -------------------------------------------
 hipError_t launch_transpose_bf16(const bf16_t* in, int64_t ld_in, int M, int C, bf16_t* out, int Mpad, hipStream_t s);
 hipError_t launch_rowsum_bf16(const bf16_t* x, int64_t ld, int R, int n, float* out, hipStream_t s);
-hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, hipStream_t s);
-hipError_t launch_gelu_bwd(const bf16_t* pre, bf16_t* d, int64_t n, hipStream_t s);
+hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, DropSpec drop, hipStream_t s);
+hipError_t launch_gelu_bwd(const bf16_t* pre, bf16_t* d, int64_t n, DropSpec drop, hipStream_t s);
 hipError_t launch_resid_gate(const float* x_in, const bf16_t* y, const float* gate, int64_t gate_bstride, float* x_out,
-                             int M, int D, int ntok, hipStream_t s);
+                             int M, int D, int ntok, DropSpec path, DropSpec elem, hipStream_t s);
 int train_nchunk(int ntok);     // token chunks per sample of the column-reduction partials
 int train_red_blocks();         // blocks (= partial sums) of the scalar reductions
 hipError_t launch_gate_bwd(const float* dx, const bf16_t* y, const float* gate, int64_t gate_bstride, bf16_t* dy,
-                           float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, hipStream_t s);
+                           float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, DropSpec path,
+                           DropSpec elem, hipStream_t s);
 hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, const float* scale, int64_t mod_bstride,
                            float* dx, int accumulate, float* part, float* dw_part, float* dshift, float* dscale,
                            int64_t dmod_bstride, float* dw, int B, int D, int ntok, int mode, hipStream_t s);
 hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
                                 const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
-                                int B, int N, int Hq, int Hkv, int npad, hipStream_t s);
+                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, hipStream_t s);
 hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
                            float loss_scale, hipStream_t s);
 hipError_t launch_grad_sqsum(const float* g, int64_t n, float* part, float* norm2, hipStream_t s);

@@ -48,6 +48,8 @@ struct jat_trainer {
   bf16_t *dy, *dh, *dxn, *dao, *dqkv, *tA, *tB, *dyf;
   int64_t o_pe_w1, o_pe_b1, o_pe_w2, o_pe_b2, o_te_w1, o_te_b1, o_te_w2, o_te_b2, o_fn, o_wf, o_bf;
   bool rms = true;
+  std::vector<float> p_drop, p_path;   // per-layer Dropout / DropPath rates (jat_trainer_set_regularisers); default 0
+  uint64_t seed = 0;                   // RNG seed of the step in flight (masks are recomputed by the backward)
   CopyJob* copy_jobs = nullptr;        // device table: fp32 master slices -> the model's fp32 operand tensors
   int n_copy_jobs = 0;
   float* dw_part = nullptr;
@@ -115,6 +117,13 @@ int input_grad(jat_trainer* tr, const bf16_t* dY, int out, const bf16_t* WT, int
   return jat_gemm(tr->m, G_OTHER, dY, out, WT, out, tr->M, in, out, EPI_BF16, e, s);
 }
 
+// mask sites of layer l (jat_rng.h): 0 attention probabilities, 1 DropPath(attn), 2 MLP after GELU, 3 MLP out, 4 DropPath(MLP)
+DropSpec site(const jat_trainer* tr, int l, int kind) {
+  const float p = (kind == 1 || kind == 4) ? tr->p_path[l] : tr->p_drop[l];
+  return jat_drop_spec(tr->seed, (uint32_t)(l * 8 + kind), p);
+}
+const DropSpec kNoDrop = {0u, 0u, 0u, 1.0f};
+
 int forward_train(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond, hipStream_t s) {
   jat_model* m = tr->m;
   const int B = tr->B, T = tr->T, ntok = tr->ntok, M = tr->M, D = m->D, Nqkv = D + 2 * m->kvD;
@@ -134,7 +143,7 @@ int forward_train(jat_trainer* tr, const float* z_t, const float* t, const float
     GemmArgs e{};
     e.out = tr->pe_pre; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok;
     JCHK(jat_gemm(m, G_OTHER, tr->a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16, e, s));
-    KCHK(launch_gelu_bf16(tr->pe_pre, tr->pe_h, (int64_t)M * m->bott, s));
+    KCHK(launch_gelu_bf16(tr->pe_pre, tr->pe_h, (int64_t)M * m->bott, kNoDrop, s));
     GemmArgs f{};
     f.out = tr->x[0]; f.ldo = D; f.bias = m->pe_b2; f.ntok = ntok;
     JCHK(jat_gemm(m, G_OTHER, tr->pe_h, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, f, s));
@@ -156,6 +165,7 @@ int forward_train(jat_trainer* tr, const float* z_t, const float* t, const float
       a.B = B; a.N = ntok; a.Hq = m->Hq; a.Hkv = m->Hkv; a.npad = tr->npad;
       a.scale_log2e = 0.125f * 1.4426950408889634f;
       a.lse = L.lse;
+      a.drop = site(tr, l, 0);
       KCHK(launch_attention(a, s));
     }
     {
@@ -163,18 +173,18 @@ int forward_train(jat_trainer* tr, const float* z_t, const float* t, const float
       e.out = L.y_attn; e.ldo = D; e.ntok = ntok;
       JCHK(jat_gemm(m, G_OUT, L.ao, D, W.wo, D, M, D, D, EPI_BF16, e, s));
     }
-    KCHK(launch_resid_gate(tr->x[l], L.y_attn, mod + 2 * D, mstride, L.x_mid, M, D, ntok, s));
+    KCHK(launch_resid_gate(tr->x[l], L.y_attn, mod + 2 * D, mstride, L.x_mid, M, D, ntok, site(tr, l, 1), kNoDrop, s));
     KCHK(launch_norm_modulate(L.x_mid, W.norm2, mod + 3 * D, mod + 4 * D, mstride, L.xn2, M, D, ntok, m->cfg.norm_mode, s));
     {
       GemmArgs e{};
       e.out = L.h_pre; e.ldo = m->mlp; e.bias = W.b1; e.ntok = ntok;
       JCHK(jat_gemm(m, G_FC1, L.xn2, D, W.w1, D, M, m->mlp, D, EPI_BF16, e, s));
-      KCHK(launch_gelu_bf16(L.h_pre, L.h_post, (int64_t)M * m->mlp, s));
+      KCHK(launch_gelu_bf16(L.h_pre, L.h_post, (int64_t)M * m->mlp, site(tr, l, 2), s));
       GemmArgs f{};
       f.out = L.y_mlp; f.ldo = D; f.bias = W.b2; f.ntok = ntok;
       JCHK(jat_gemm(m, G_FC2, L.h_post, m->mlp, W.w2, m->mlp, M, D, m->mlp, EPI_BF16, f, s));
     }
-    KCHK(launch_resid_gate(L.x_mid, L.y_mlp, mod + 5 * D, mstride, tr->x[l + 1], M, D, ntok, s));
+    KCHK(launch_resid_gate(L.x_mid, L.y_mlp, mod + 5 * D, mstride, tr->x[l + 1], M, D, ntok, site(tr, l, 4), site(tr, l, 3), s));
   }
   KCHK(launch_norm_modulate(tr->x[m->depth], m->final_norm, nullptr, nullptr, 0, tr->xnf, M, D, ntok, m->cfg.norm_mode, s));
   {
@@ -202,20 +212,22 @@ int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipSt
     const float* mod = tr->mod + (int64_t)l * 6 * D;
     float* dmod = tr->dmod + (int64_t)l * 6 * D;
     // x_out = x_mid + gate_mlp * mlp(norm2(x_mid) * (1 + scale_mlp) + shift_mlp)          jat_audiosr_v3.py:303-306
-    KCHK(launch_gate_bwd(tr->dx, L.y_mlp, mod + 5 * D, mstride, tr->dy, tr->part, dmod + 5 * D, mstride, B, D, ntok, s));
+    KCHK(launch_gate_bwd(tr->dx, L.y_mlp, mod + 5 * D, mstride, tr->dy, tr->part, dmod + 5 * D, mstride, B, D, ntok,
+                         site(tr, l, 4), site(tr, l, 3), s));
     JCHK(input_grad(tr, tr->dy, D, L.w2T, m->mlp, tr->dh, s));
     JCHK(weight_grad(tr, tr->dy, D, L.h_post, m->mlp, G + L.o_w2, G + L.o_b2, s));
-    KCHK(launch_gelu_bwd(L.h_pre, tr->dh, (int64_t)M * m->mlp, s));
+    KCHK(launch_gelu_bwd(L.h_pre, tr->dh, (int64_t)M * m->mlp, site(tr, l, 2), s));
     JCHK(input_grad(tr, tr->dh, m->mlp, L.w1T, D, tr->dxn, s));
     JCHK(weight_grad(tr, tr->dh, m->mlp, L.xn2, D, G + L.o_w1, G + L.o_b1, s));
     KCHK(launch_norm_bwd(L.x_mid, tr->dxn, m->layers[l].norm2, mod + 4 * D, mstride, tr->dx, 1, tr->part, tr->dw_part, dmod + 3 * D,
                          dmod + 4 * D, mstride, tr->rms ? G + L.o_n2 : nullptr, B, D, ntok, mode, s));
     // x_mid = x_in + gate_msa * out_proj(attn(norm1(x_in) * (1 + scale_msa) + shift_msa))   :297-300
-    KCHK(launch_gate_bwd(tr->dx, L.y_attn, mod + 2 * D, mstride, tr->dy, tr->part, dmod + 2 * D, mstride, B, D, ntok, s));
+    KCHK(launch_gate_bwd(tr->dx, L.y_attn, mod + 2 * D, mstride, tr->dy, tr->part, dmod + 2 * D, mstride, B, D, ntok,
+                         site(tr, l, 1), kNoDrop, s));
     JCHK(input_grad(tr, tr->dy, D, L.woT, D, tr->dao, s));
     JCHK(weight_grad(tr, tr->dy, D, L.ao, D, G + L.o_o, nullptr, s));
     KCHK(launch_attention_bwd(L.q, L.k, L.vt, L.ao, tr->dao, L.lse, tr->delta, tr->dqkv, m->rope_cos, m->rope_sin, B, ntok,
-                              m->Hq, m->Hkv, tr->npad, s));
+                              m->Hq, m->Hkv, tr->npad, site(tr, l, 0), s));
     JCHK(input_grad(tr, tr->dqkv, Nqkv, L.wqkvT, D, tr->dxn, s));
     JCHK(weight_grad(tr, tr->dqkv, Nqkv, L.xn1, D, tr->dwqkv, nullptr, s));
     KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, s));
@@ -226,7 +238,7 @@ int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipSt
   KCHK(launch_cast_bf16(tr->dx, tr->dy, (int64_t)M * D, s));
   JCHK(input_grad(tr, tr->dy, D, tr->pe_w2T, m->bott, tr->dh, s));
   JCHK(weight_grad(tr, tr->dy, D, tr->pe_h, m->bott, G + tr->o_pe_w2, G + tr->o_pe_b2, s));
-  KCHK(launch_gelu_bwd(tr->pe_pre, tr->dh, (int64_t)M * m->bott, s));
+  KCHK(launch_gelu_bwd(tr->pe_pre, tr->dh, (int64_t)M * m->bott, kNoDrop, s));
   JCHK(weight_grad(tr, tr->dh, m->bott, tr->a_patch, m->Kp, G + tr->o_pe_w1, G + tr->o_pe_b1, s));
   // adaLN modulation Linear(SiLU(t_emb)) of every block (:275-278), then the t_embedder MLP (:364-369); fp32, B rows
   for (int l = 0; l < m->depth; ++l) {
@@ -265,6 +277,8 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
   tr->Mpad = (int)align_up((size_t)tr->M, 64); tr->npad = (int)align_up((size_t)ntok, 64);
   tr->P = params_flat; tr->G = grads_flat; tr->m1 = exp_avg; tr->m2 = exp_avg_sq; tr->total = total;
   tr->rms = m->cfg.norm_mode == JAT_NORM_RMS_W;
+  tr->p_drop.assign(m->depth, 0.f);
+  tr->p_path.assign(m->depth, 0.f);
   const int D = m->D, depth = m->depth, mlp = m->mlp, bott = m->bott, kvD = m->kvD, Nqkv = D + 2 * kvD;
   const int M = tr->M, Mpad = tr->Mpad;
 
@@ -400,6 +414,17 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
   return JAT_OK;
 }
 
+extern "C" int jat_trainer_set_regularisers(jat_trainer* tr, const float* dropout, const float* drop_path) {
+  if (!tr || !dropout || !drop_path) return fail(JAT_E_INVALID, "null argument");
+  for (int l = 0; l < tr->m->depth; ++l) {
+    if (!(dropout[l] >= 0.f && dropout[l] < 1.f) || !(drop_path[l] >= 0.f && drop_path[l] < 1.f))
+      return fail(JAT_E_INVALID, "layer %d: rates must be in [0, 1)", l);
+    tr->p_drop[l] = dropout[l];
+    tr->p_path[l] = drop_path[l];
+  }
+  return JAT_OK;
+}
+
 extern "C" int jat_trainer_workspace_bytes(const jat_trainer* tr, size_t* out) {
   if (!tr || !out) return fail(JAT_E_INVALID, "null argument");
   *out = tr->blob_bytes;
@@ -422,11 +447,12 @@ extern "C" int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float*
 }
 
 extern "C" int jat_trainer_fwd_bwd(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond,
-                                   const float* target, float loss_scale, float* loss_out, float* x_pred_out,
-                                   void* stream) {
+                                   const float* target, float loss_scale, uint64_t rng_seed, float* loss_out,
+                                   float* x_pred_out, void* stream) {
   if (!tr || !z_t || !t || !x_cond || !target) return fail(JAT_E_INVALID, "null argument");
   if (!tr->m->loaded) return fail(JAT_E_STATE, "weights not loaded");
   hipStream_t s = (hipStream_t)stream;
+  tr->seed = rng_seed;
   JCHK(forward_train(tr, z_t, t, x_cond, s));
   JCHK(backward_train(tr, target, loss_scale, s));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, tr->scal, 4, hipMemcpyDeviceToDevice, s));

@@ -4,6 +4,7 @@
 // by transpose_bf16_kernel.  Everything here is either HBM-bound row/column work or the attention backward.
 // All reductions are fixed-order (partials + a finishing kernel): no atomics, a step is bit-reproducible.
 #include "jat_kernels.h"
+#include "jat_rng.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -95,17 +96,24 @@ __device__ __forceinline__ float gelu_t(float x) { return 0.5f * x * (1.0f + erf
 __device__ __forceinline__ float dgelu_t(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
-__global__ void __launch_bounds__(256) gelu_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t n8) {
+// out = dropout(gelu(in)): element e is scaled by jat_drop_mult(drop, e)   (nn.Dropout after nn.GELU, :268-269)
+__global__ void __launch_bounds__(256) gelu_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t n8,
+                                                        const DropSpec drop) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
   float f[8];
   unpack8(*(const u32x4_t*)(in + i * 8), f);
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = gelu_t(f[j]);
+  if (drop.thresh) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= jat_drop_mult(drop, (uint64_t)(i * 8 + j));
+  }
   *(u32x4_t*)(out + i * 8) = pack8(f);
 }
-// dpre = dpost * gelu'(pre), in place on dpost
-__global__ void __launch_bounds__(256) gelu_bwd_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ d, int64_t n8) {
+// dpre = dpost * mask * gelu'(pre), in place on dpost
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ d, int64_t n8,
+                                                       const DropSpec drop) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
   float f[8], g[8];
@@ -113,23 +121,28 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const bf16_t* __restrict_
   unpack8(*(const u32x4_t*)(d + i * 8), g);
 #pragma unroll
   for (int j = 0; j < 8; ++j) g[j] *= dgelu_t(f[j]);
+  if (drop.thresh) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= jat_drop_mult(drop, (uint64_t)(i * 8 + j));
+  }
   *(u32x4_t*)(d + i * 8) = pack8(g);
 }
-hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, hipStream_t s) {
+hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, DropSpec drop, hipStream_t s) {
   if (n % 8 != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gelu_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, in, out, n / 8);
+  hipLaunchKernelGGL(gelu_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, in, out, n / 8, drop);
   return hipGetLastError();
 }
-hipError_t launch_gelu_bwd(const bf16_t* pre, bf16_t* d, int64_t n, hipStream_t s) {
+hipError_t launch_gelu_bwd(const bf16_t* pre, bf16_t* d, int64_t n, DropSpec drop, hipStream_t s) {
   if (n % 8 != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, pre, d, n / 8);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, pre, d, n / 8, drop);
   return hipGetLastError();
 }
 
 // ---- gated residual forward with the branch output kept: x_out = x_in + gate[b] * y   (jat_audiosr_v3.py:300,306) --
 __global__ void __launch_bounds__(256) resid_gate_kernel(const float* __restrict__ x_in, const bf16_t* __restrict__ y,
                                                          const float* __restrict__ gate, int64_t gate_bstride,
-                                                         float* __restrict__ x_out, int M, int D, int ntok) {
+                                                         float* __restrict__ x_out, int M, int D, int ntok,
+                                                         const DropSpec path, const DropSpec elem) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread = 8 columns
   const int per_row = D / 8;
   if (i >= (int64_t)M * per_row) return;
@@ -137,6 +150,11 @@ __global__ void __launch_bounds__(256) resid_gate_kernel(const float* __restrict
   const float* g = gate + (int64_t)(row / ntok) * gate_bstride + c;
   float f[8];
   unpack8(*(const u32x4_t*)(y + (int64_t)row * D + c), f);
+  if (path.thresh | elem.thresh) {   // DropPath: per-sample scale of the branch; Dropout: per-element scale of y
+    const float pm = path.thresh ? jat_drop_mult(path, (uint64_t)(row / ntok)) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= pm * (elem.thresh ? jat_drop_mult(elem, (uint64_t)row * D + c + j) : 1.0f);
+  }
   const f32x4_t a0 = *(const f32x4_t*)(x_in + (int64_t)row * D + c), a1 = *(const f32x4_t*)(x_in + (int64_t)row * D + c + 4);
   const f32x4_t g0 = *(const f32x4_t*)g, g1 = *(const f32x4_t*)(g + 4);
   f32x4_t o0, o1;
@@ -146,10 +164,10 @@ __global__ void __launch_bounds__(256) resid_gate_kernel(const float* __restrict
   *(f32x4_t*)(x_out + (int64_t)row * D + c + 4) = o1;
 }
 hipError_t launch_resid_gate(const float* x_in, const bf16_t* y, const float* gate, int64_t gate_bstride, float* x_out,
-                             int M, int D, int ntok, hipStream_t s) {
+                             int M, int D, int ntok, DropSpec path, DropSpec elem, hipStream_t s) {
   const int64_t n = (int64_t)M * (D / 8);
   hipLaunchKernelGGL(resid_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x_in, y, gate, gate_bstride,
-                     x_out, M, D, ntok);
+                     x_out, M, D, ntok, path, elem);
   return hipGetLastError();
 }
 
@@ -158,11 +176,14 @@ hipError_t launch_resid_gate(const float* x_in, const bf16_t* y, const float* ga
 constexpr int TOKC = 16;
 __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ y,
                                                        const float* __restrict__ gate, int64_t gate_bstride,
-                                                       bf16_t* __restrict__ dy, float* __restrict__ part, int D, int ntok) {
+                                                       bf16_t* __restrict__ dy, float* __restrict__ part, int D, int ntok,
+                                                       const DropSpec path, const DropSpec elem) {
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int t0 = chunk * TOKC, t1 = min(t0 + TOKC, ntok);
+  const float pm = path.thresh ? jat_drop_mult(path, (uint64_t)b) : 1.0f;
   for (int c = threadIdx.x * 4; c < D; c += 1024) {
-    const f32x4_t g = *(const f32x4_t*)(gate + (int64_t)b * gate_bstride + c);
+    f32x4_t g = *(const f32x4_t*)(gate + (int64_t)b * gate_bstride + c);
+    g[0] *= pm; g[1] *= pm; g[2] *= pm; g[3] *= pm;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     for (int t = t0; t < t1; ++t) {
       const int64_t row = (int64_t)b * ntok + t;
@@ -170,10 +191,17 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
       const u32x2_t yy = *(const u32x2_t*)(y + row * D + c);
       const float y0 = __builtin_bit_cast(float, yy[0] << 16), y1 = __builtin_bit_cast(float, yy[0] & 0xffff0000u);
       const float y2 = __builtin_bit_cast(float, yy[1] << 16), y3 = __builtin_bit_cast(float, yy[1] & 0xffff0000u);
-      acc[0] += d[0] * y0; acc[1] += d[1] * y1; acc[2] += d[2] * y2; acc[3] += d[3] * y3;
+      float e0 = pm, e1 = pm, e2 = pm, e3 = pm;   // d(branch)/d(gate*y) multipliers: DropPath x element dropout
+      float h0 = 1.f, h1 = 1.f, h2 = 1.f, h3 = 1.f;
+      if (elem.thresh) {
+        const uint64_t e = (uint64_t)row * D + c;
+        h0 = jat_drop_mult(elem, e); h1 = jat_drop_mult(elem, e + 1); h2 = jat_drop_mult(elem, e + 2); h3 = jat_drop_mult(elem, e + 3);
+      }
+      e0 *= h0; e1 *= h1; e2 *= h2; e3 *= h3;
+      acc[0] += d[0] * y0 * e0; acc[1] += d[1] * y1 * e1; acc[2] += d[2] * y2 * e2; acc[3] += d[3] * y3 * e3;
       u32x2_t o;
-      o[0] = (unsigned)f2bf_t(d[0] * g[0]) | ((unsigned)f2bf_t(d[1] * g[1]) << 16);
-      o[1] = (unsigned)f2bf_t(d[2] * g[2]) | ((unsigned)f2bf_t(d[3] * g[3]) << 16);
+      o[0] = (unsigned)f2bf_t(d[0] * g[0] * h0) | ((unsigned)f2bf_t(d[1] * g[1] * h1) << 16);
+      o[1] = (unsigned)f2bf_t(d[2] * g[2] * h2) | ((unsigned)f2bf_t(d[3] * g[3] * h3) << 16);
       *(u32x2_t*)(dy + row * D + c) = o;
     }
     *(f32x4_t*)(part + ((int64_t)b * nchunk + chunk) * D + c) = acc;
@@ -199,9 +227,11 @@ __global__ void __launch_bounds__(256) reduce_chunks_kernel(const float* __restr
 }
 int train_nchunk(int ntok) { return (ntok + TOKC - 1) / TOKC; }
 hipError_t launch_gate_bwd(const float* dx, const bf16_t* y, const float* gate, int64_t gate_bstride, bf16_t* dy,
-                           float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, hipStream_t s) {
+                           float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, DropSpec path,
+                           DropSpec elem, hipStream_t s) {
   const int nchunk = train_nchunk(ntok);
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(nchunk, B), dim3(256), 0, s, dx, y, gate, gate_bstride, dy, part, D, ntok);
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(nchunk, B), dim3(256), 0, s, dx, y, gate, gate_bstride, dy, part, D, ntok, path,
+                     elem);
   hipLaunchKernelGGL(reduce_chunks_kernel, dim3((D + 255) / 256, B), dim3(256), 0, s, part, nchunk, (int64_t)D, dgate,
                      dgate_bstride, B, D, 0);
   return hipGetLastError();
@@ -365,6 +395,7 @@ struct AttnBwdArgs {
   int64_t ldq, ldk, ldg;
   int B, N, Hq, Hkv, npad, D, kvD;
   float scale_log2e, scale;
+  DropSpec drop;   // attention-probability dropout (:175): element ((b*Hq + h)*N + i)*N + j
 };
 
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t ld, int r0, int N,
@@ -475,7 +506,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pr[r] = exp2f(sacc[nt][r] * p.scale_log2e - l2[r]);
-          ds[r] = pr[r] * (pacc[nt][r] - de[r]) * p.scale;
+          float dp = pacc[nt][r];
+          if (p.drop.thresh) {   // O = (P o m) V:  dV uses P o m,  dP = (dO V^T) o m,  delta = rowsum(dO o O) unchanged
+            const int64_t i = i0 + wave * 16 + fg * 4 + r, j = j0 + nt * 16 + fr;
+            const float mm = jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
+            dp *= mm;
+            ds[r] = pr[r] * (dp - de[r]) * p.scale;
+            pr[r] *= mm;
+          } else {
+            ds[r] = pr[r] * (dp - de[r]) * p.scale;
+          }
         }
         u32x2_t a, d;
         a[0] = (unsigned)f2bf_t(pr[0]) | ((unsigned)f2bf_t(pr[1]) << 16);
@@ -534,7 +574,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pr = exp2f(sacc[nt][r] * p.scale_log2e - l2[nt]);
-        ds[r] = pr * (pacc[nt][r] - de[nt]) * p.scale;
+        float dp = pacc[nt][r];
+        if (p.drop.thresh) {
+          const int64_t i = i0 + nt * 16 + fr, j = j0 + wave * 16 + fg * 4 + r;
+          dp *= jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
+        }
+        ds[r] = pr * (dp - de[nt]) * p.scale;
       }
       u32x2_t d;
       d[0] = (unsigned)f2bf_t(ds[0]) | ((unsigned)f2bf_t(ds[1]) << 16);
@@ -571,9 +616,10 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 
 hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
                                 const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
-                                int B, int N, int Hq, int Hkv, int npad, hipStream_t s) {
+                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, hipStream_t s) {
   if (Hq % Hkv != 0 || npad % 64 != 0 || npad < N || N > 2048) return hipErrorInvalidValue;
   AttnBwdArgs a;
+  a.drop = drop;
   a.q = q; a.k = k; a.vt = vt; a.dout = dout; a.lse = lse; a.delta = delta; a.dqkv = dqkv;
   a.rope_cos = rope_cos; a.rope_sin = rope_sin;
   a.D = Hq * 64; a.kvD = Hkv * 64; a.ldq = a.D; a.ldk = a.kvD; a.ldg = a.D + 2 * a.kvD;

@@ -9,8 +9,9 @@ One process per GPU; the only collective is the gradient all-reduce between `jat
 code below owns the hyper-parameters and the RNG draws (torch generators: data, not arithmetic); everything numeric —
 normalisation, noise mix, forward, loss, backward, clip, AdamW — runs in the HIP library (include/jat_hip.h).
 
-Not implemented: Dropout / DropPath (jat_audiosr_v3.py:38-64,139,269-271) — `Trainer` refuses a model constructed
-with non-zero rates unless `allow_missing_regularisers=True`, in which case the step is the reference's with both at 0.
+Dropout (attention probabilities, MLP x2) and DropPath (jat_audiosr_v3.py:38-64,139,175,269-271,300,306) follow the
+rates the model was constructed with; their masks come from a counter-based generator keyed by (trainer seed, step,
+layer, site, element) inside the kernels — nn.Dropout / drop_path semantics, not torch's Philox stream.
 """
 from __future__ import annotations
 
@@ -100,13 +101,8 @@ class Trainer:
 
     def __init__(self, model, batch_size, frames, lr=5e-5, weight_decay=0.1, betas=(0.9, 0.999), eps=1e-8,
                  grad_clip=1.0, cfg_dropout_prob=0.1, condition_noise_ratio=0.02, use_adaptive_noise=True,
-                 warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None,
-                 allow_missing_regularisers=False):
+                 warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None):
         L.require_gpu()
-        rates = [getattr(b, "dropout_rate", 0.0) for b in model.blocks] + [getattr(b, "drop_path_rate", 0.0) for b in model.blocks]
-        if any(r > 0 for r in rates) and not allow_missing_regularisers:
-            raise NotImplementedError("Dropout / DropPath are not implemented in the HIP training step; construct the "
-                                      "model with dropout=0, drop_path_rate=0 or pass allow_missing_regularisers=True")
         self.model = model
         self.B, self.T = int(batch_size), int(frames)
         self.base_lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -148,6 +144,27 @@ class Trainer:
                                            L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), total, self.B, self.T,
                                            L.stream_ptr(), C.byref(self.ptr)))
         self._scal = torch.zeros(2, dtype=torch.float32, device=dev)   # loss, scaled grad norm
+        self.mask_seed = 0x9E3779B97F4A7C15 if seed is None else int(seed)
+        self.set_regularisers([getattr(b, "dropout_rate", 0.0) for b in model.blocks],
+                              [getattr(b, "drop_path_rate", 0.0) for b in model.blocks])
+
+    def set_regularisers(self, dropout, drop_path):
+        """Per-layer nn.Dropout p and DropPath rate (defaults: what the model was constructed with,
+        jat_audiosr_v3.py:372-377)."""
+        n = len(self.model.blocks)
+        if len(dropout) != n or len(drop_path) != n:
+            raise ValueError(f"need {n} per-layer rates")
+        self.dropout, self.drop_path = [float(x) for x in dropout], [float(x) for x in drop_path]
+        L.check(L.lib().jat_trainer_set_regularisers(self.ptr, (C.c_float * n)(*self.dropout), (C.c_float * n)(*self.drop_path)))
+
+    def step_seed(self, step=None):
+        """64-bit mask seed of a step: splitmix64 of (trainer seed, step index, rank)."""
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        x = (self.mask_seed + 0x9E3779B97F4A7C15 * ((self.global_step if step is None else step) * 4096 + rank + 1)) & (2 ** 64 - 1)
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        return x ^ (x >> 31)
 
     def __del__(self):
         try:
@@ -191,15 +208,18 @@ class Trainer:
                                             int(self.use_adaptive_noise), L.ptr(keep), L.ptr(t), L.ptr(z_t), L.stream_ptr()))
         return z_t, t, cond
 
-    def forward_backward(self, z_t, t, cond, target, want_pred=False):
-        """pred = model(z_t, t, cond); loss = mse_loss(pred, target); backward -> self.grads (scaled by scaler.scale)."""
+    def forward_backward(self, z_t, t, cond, target, want_pred=False, mask_seed=None):
+        """pred = model(z_t, t, cond); loss = mse_loss(pred, target); backward -> self.grads (scaled by scaler.scale).
+        mask_seed: 64-bit seed of this step's Dropout / DropPath masks (default: `step_seed()`)."""
         for x in (z_t, cond, target):
             if tuple(x.shape) != (self.B, self.model.input_channels, self.T) or x.dtype != torch.float32 or not x.is_cuda:
                 raise ValueError(f"expected fp32 CUDA [{self.B}, {self.model.input_channels}, {self.T}], got "
                                  f"{tuple(x.shape)} {x.dtype} on {x.device}")
         pred = torch.empty_like(z_t) if want_pred else None
         L.check(L.lib().jat_trainer_fwd_bwd(self.ptr, L.ptr(z_t.contiguous()), L.ptr(t.contiguous()), L.ptr(cond.contiguous()),
-                                            L.ptr(target.contiguous()), float(self.scaler.scale), L.ptr(self._scal),
+                                            L.ptr(target.contiguous()), float(self.scaler.scale),
+                                            C.c_uint64(self.step_seed() if mask_seed is None else int(mask_seed)),
+                                            L.ptr(self._scal),
                                             L.ptr(pred) if want_pred else None, L.stream_ptr()))
         return pred
 
@@ -258,6 +278,6 @@ class Trainer:
         ck = dict(epoch=epoch, global_step=self.global_step, best_val_loss=best_val_loss,
                   model_state_dict={k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
                   optimizer_state_dict=self.optimizer_state_dict(), scaler_state_dict=self.scaler.state_dict(),
-                  config=dict(self.model.config(), dropout=0.0, drop_path_rate=0.0))
+                  config=dict(self.model.config(), dropout=max(self.dropout), drop_path_rate=max(self.drop_path)))
         torch.save(ck, path)
         return ck

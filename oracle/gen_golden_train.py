@@ -126,6 +126,71 @@ def train_case(name, cfg_name, B, T, t_list, mask_list, norm="rms", salt=0, lr_r
           f"loss32-loss64={rec['loss32'] - rec['loss64']:.2e} ({sz / 1024:.0f} KiB)")
 
 
+def dropout_case(name, cfg_name, B, T, t_list, seed, dropout=0.1, drop_path_rate=0.05, salt=0, strides=(7, 5)):
+    """Train-mode Dropout / DropPath of the REFERENCE with injected masks.  torch's Philox stream cannot be reproduced
+    on another device, so the masks come from the counter-based generator of csrc/jat_rng.h (numpy mirror
+    oracle.jat_oracle_train.drop_mult) and are injected at the reference's own random calls, in call order:
+    F.dropout(attn_weights) jat_audiosr_v3.py:175, torch.rand in drop_path :47 (attention branch, :300), F.dropout x2 in
+    the MLP :269,271, torch.rand in drop_path (MLP branch, :306).  What is pinned is the SEMANTICS (where a mask applies,
+    the 1/(1-p) scaling, how gradients flow through it)."""
+    from oracle import jat_oracle_train as OT
+    cfg = recipe.CONFIGS[cfg_name]
+    depth, D, Hq = cfg["depth"], cfg["hidden_size"], cfg["num_q_heads"]
+    mlp = int(D * cfg.get("mlp_ratio", 4.0))
+    hr, lr, noise = step_inputs(cfg, B, T, salt)
+    t = np.asarray(t_list, dtype=np.float32)
+    N = -(-T // 4)
+    dpr = [float(x) for x in torch.linspace(0, drop_path_rate, depth)]
+    plan = OT.DropPlan(seed, [dropout] * depth, dpr)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.models.jat_audiosr_v3 import JaT_AudioSR_V3
+        m = JaT_AudioSR_V3(**cfg, dropout=dropout, drop_path_rate=drop_path_rate)
+    sd = {k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg, "rms", salt).items()}
+    m.load_state_dict(sd, strict=False)
+    m = m.double().train()
+    state = {"layer": 0, "drop_calls": 0, "rand_calls": 0}
+    kinds_drop = [0, 2, 3]
+
+    def fake_dropout(x, p=0.5, training=True, inplace=False):
+        assert training and abs(p - dropout) < 1e-12
+        layer, c = divmod(state["drop_calls"], 3)
+        state["drop_calls"] += 1
+        mult = plan.mult(layer, kinds_drop[c], tuple(x.shape))
+        return x * torch.from_numpy(mult).to(x.dtype)
+
+    def fake_rand(shape, dtype=None, device=None):
+        # layers with drop_prob == 0 never call torch.rand (nn.Identity, :282); the others call it twice, in order
+        live = [i for i in range(depth) if dpr[i] > 0]
+        layer, c = live[state["rand_calls"] // 2], state["rand_calls"] % 2
+        state["rand_calls"] += 1
+        keep = plan.mult(layer, 1 if c == 0 else 4, (shape[0],)) > 0
+        return torch.from_numpy(np.where(keep, 0.999, 0.0)).to(dtype).reshape(shape)   # floor(keep_prob + u) = keep
+
+    real_drop, real_rand = torch.nn.functional.dropout, torch.rand
+    torch.nn.functional.dropout, torch.rand = fake_dropout, fake_rand
+    try:
+        hr_t, lr_t, nz = (torch.from_numpy(a).double() for a in (hr, lr, noise))
+        tt = torch.from_numpy(t).double()
+        tv = tt.view(-1, 1, 1)
+        z_t = tv * hr_t + (1 - tv) * nz
+        pred = m(z_t, tt, lr_t)
+        loss = torch.nn.functional.mse_loss(pred, hr_t)
+        loss.backward()
+    finally:
+        torch.nn.functional.dropout, torch.rand = real_drop, real_rand
+    assert state["drop_calls"] == 3 * depth and state["rand_calls"] == 2 * sum(1 for p in dpr if p > 0)
+    rec = {"loss64": np.float64(loss.item()), "pred_l2": np.float64(pred.detach().norm().item())}
+    for k, p in m.named_parameters():
+        rec["g_" + k] = sub(p.grad.numpy(), strides)
+        rec["gl2_" + k] = np.float64(p.grad.norm().item())
+    rec["meta"] = json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, t=[float(v) for v in t], norm="rms", salt=salt,
+                                  seed=seed, dropout=dropout, drop_path_rate=drop_path_rate, drop_path=dpr,
+                                  full_limit=FULL_LIMIT, strides=strides, torch=torch.__version__,
+                                  names=[k for k, _ in m.named_parameters()], mlp=mlp, N=N, Hq=Hq))
+    np.savez_compressed(os.path.join(GOLD, f"train_{name}.npz"), **rec)
+    print(f"[golden] train_{name}: loss={rec['loss64']:.6f} (dropout {dropout}, drop_path {dpr})")
+
+
 def u_shape_case():
     src = open(os.path.join(REF, "train_ddp_v3m2.py"), encoding="utf-8").read()
     fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "u_shaped_timestep_sampling"]
@@ -154,6 +219,11 @@ def main(which):
     if allc or "tiny" in which:
         train_case("tiny_T128", "tiny", 2, 128, [0.2, 0.9], [False, True], strides=(61, 53))
         train_case("tiny_T1378", "tiny", 1, 1378, [0.4], [False], salt=1, strides=(61, 53))
+    if allc or "drop" in which:
+        dropout_case("micro_drop_T24", "micro", 3, 24, [0.1, 0.5, 0.85], seed=0x0123456789ABCDEF, dropout=0.1,
+                     drop_path_rate=0.4)
+        dropout_case("tiny_drop_T128", "tiny", 2, 128, [0.2, 0.9], seed=77, dropout=0.1, drop_path_rate=0.3,
+                     strides=(61, 53))
     if allc or "misc" in which:
         u_shape_case()
 

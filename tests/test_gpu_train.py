@@ -8,6 +8,7 @@ relative error of order 2^-8 per bf16 rounding on its path; per-tensor rel-L2 ag
 GRAD_TOL, and the global quantities (loss, gradient norm) much tighter.
 """
 import json
+import math
 
 import numpy as np
 import pytest
@@ -21,7 +22,7 @@ from helpers import load_golden, rel_l2  # noqa: E402
 from jatsr_amd.model import JaT_AudioSR_V2, JaT_AudioSR_V3  # noqa: E402
 from jatsr_amd.train import Trainer  # noqa: E402
 
-GRAD_TOL = 4e-2        # per-tensor rel-L2 of a gradient vs the fp64 reference
+GRAD_TOL = 3e-2        # per-tensor rel-L2 of a gradient vs the fp64 reference
 GRAD_TOL_SMALL = 8e-2  # tensors whose gradient norm is < 1e-3 of the global norm (dominated by rounding noise)
 LOSS_TOL, GNORM_TOL = 2e-3, 1e-2
 
@@ -169,3 +170,82 @@ def test_cond_noise_and_training_loop_reduce_loss():
     assert tr.global_step == 12
     ck = tr.optimizer_state_dict()
     assert len(ck["state"]) == len(meta["names"]) and float(ck["state"][0]["step"]) == 12.0
+
+
+@pytest.mark.parametrize("cfg_name,B,T,norm,salt", [("micro", 5, 70, "rms", 11), ("micro", 1, 9, "ln", 12),
+                                                     ("tiny", 3, 260, "rms", 13)])
+def test_train_step_vs_numpy_oracle(cfg_name, B, T, norm, salt):
+    """Shapes and seeds outside the fixtures (odd batch, T % 4 != 0, N not a multiple of 16 / 64): HIP gradients vs the
+    numpy oracle's hand-derived fp64 backward (itself pinned to the reference in tests/test_train_cpu.py)."""
+    from oracle import jat_oracle_train as OT
+    cfg = recipe.CONFIGS[cfg_name]
+    C = cfg["input_channels"]
+    meta = dict(cfg=cfg_name, norm=norm, salt=salt, B=B, T=T, lr=1e-4, wd=0.1, clip=1.0)
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    z_t = recipe.gaussian("zt", (B, C, T), salt)
+    cond = recipe.gaussian("cond", (B, C, T), salt + 1)
+    target = recipe.gaussian("target", (B, C, T), salt + 2)
+    t = np.linspace(0.03, 0.97, B).astype(np.float32)
+    tr.forward_backward(cuda(z_t), cuda(t), cuda(cond), cuda(target))
+    sd = recipe.make_state_dict(cfg, norm, salt)
+    loss, grads, _ = OT.TrainOracle(cfg, sd, norm).loss_and_grads(z_t, t, cond, target)
+    assert abs(float(tr._scal[0]) - loss) <= LOSS_TOL * loss
+    gn = math.sqrt(sum(float((g * g).sum()) for g in grads.values()))
+    worst = 0.0
+    for k, g in grads.items():
+        r = rel_l2(tr.grad(k).cpu().numpy(), g)
+        tol = GRAD_TOL if np.linalg.norm(g) >= 1e-3 * gn else GRAD_TOL_SMALL
+        worst = max(worst, r / tol)
+        assert r <= tol, f"{k}: {r:.3e}"
+    print(f"{cfg_name} B={B} T={T} {norm}: loss {loss:.5f}, worst gradient at {worst:.2f} of tolerance")
+
+
+@pytest.mark.parametrize("name", ["train_micro_drop_T24", "train_tiny_drop_T128"])
+def test_dropout_and_droppath_vs_reference_golden(name):
+    """Train-mode regularisers: the fixture is the REFERENCE run with the counter-based masks injected at its own
+    random calls (oracle/gen_golden_train.py `dropout_case`); the kernels regenerate the same masks from the seed."""
+    z, meta = load_golden(name)
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    m, tr = make_trainer(dict(meta, lr=1e-4, wd=0.1, clip=1.0), use_grad_scaler=False, condition_noise_ratio=0.0)
+    tr.set_regularisers([meta["dropout"]] * cfg["depth"], meta["drop_path"])
+    C, B, T, salt = cfg["input_channels"], meta["B"], meta["T"], meta["salt"]
+    hr = cuda(recipe.gaussian("train_hr", (B, C, T), salt + 300))
+    lr = cuda(recipe.gaussian("train_lr", (B, C, T), salt + 301))
+    noise = cuda(recipe.gaussian("train_noise", (B, C, T), salt + 302))
+    t = cuda(np.asarray(meta["t"], np.float32))
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=torch.zeros(B, dtype=torch.bool), t=t)
+    tr.forward_backward(z_t, t2, cond, hr, mask_seed=meta["seed"])
+    loss = float(tr._scal[0])
+    assert abs(loss - float(z["loss64"])) <= LOSS_TOL * float(z["loss64"]), (loss, float(z["loss64"]))
+    gn_ref = math.sqrt(sum(float(z["gl2_" + k]) ** 2 for k in meta["names"]))
+    worst = ("", 0.0)
+    for k in meta["names"]:
+        g = tr.grad(k).cpu().numpy()
+        ref_l2 = float(z["gl2_" + k])
+        r = rel_l2(gsub(g, meta), z["g_" + k])
+        tol = GRAD_TOL if ref_l2 >= 1e-3 * gn_ref else GRAD_TOL_SMALL
+        if r / tol > worst[1]:
+            worst = (k, r / tol)
+        assert r <= tol, f"{k}: grad rel-L2 {r:.3e}"
+    print(f"{name}: loss {loss:.6f} (ref {float(z['loss64']):.6f}); worst tensor {worst[0]} at {worst[1]:.2f} of tolerance")
+    # a different seed gives a different step; the same seed the same step, bit for bit
+    g0 = tr.grads.clone()
+    tr.forward_backward(z_t, t2, cond, hr, mask_seed=meta["seed"])
+    assert torch.equal(tr.grads, g0)
+    tr.forward_backward(z_t, t2, cond, hr, mask_seed=meta["seed"] + 1)
+    assert not torch.equal(tr.grads, g0)
+
+
+def test_mask_statistics_through_the_model():
+    """With the MLP output dropout as the only active site and gate-weighted branches, the expected prediction is
+    unchanged (inverted dropout): the mean over many seeds approaches the no-dropout prediction."""
+    z, meta = load_golden("train_micro_T24")
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    base = tr.forward_backward(z_t, t2, cond, hr, want_pred=True).clone()
+    tr.set_regularisers([0.0, 0.0], [0.0, 0.5])
+    preds = torch.stack([tr.forward_backward(z_t, t2, cond, hr, want_pred=True, mask_seed=s) for s in range(64)])
+    kinds = {tuple(bool((p[b] - base[b]).abs().max() > 1e-6) for b in range(p.shape[0])) for p in preds}
+    assert len(kinds) > 1                      # per-sample DropPath decisions vary with the seed
+    assert rel_l2(preds.mean(0).cpu().numpy(), base.cpu().numpy()) < 0.35

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--T", type=int, default=512)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--drop-path", type=float, default=0.05)
     ap.add_argument("--split", action="store_true", help="time fwd+bwd and the optimiser separately")
     args = ap.parse_args()
     import numpy as np
@@ -31,7 +33,7 @@ def main():
 
     cfg = recipe.CONFIGS[args.config]
     C = cfg["input_channels"]
-    model = jatsr_amd.JaT_AudioSR_V3(**cfg, dropout=0.0, drop_path_rate=0.0)
+    model = jatsr_amd.JaT_AudioSR_V3(**cfg, dropout=args.dropout, drop_path_rate=args.drop_path)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg).items()}, strict=False)
     model = model.to("cuda")
     tr = Trainer(model, batch_size=args.B, frames=args.T, seed=1)
