@@ -1,6 +1,6 @@
 // Counter-based dropout masks for the training step (jat_audiosr_v3.py:38-64,139,175,269-271).
 // A mask element is a pure function of (step seed, site, element index): the backward recomputes it, nothing is stored.
-// oracle/jat_oracle_train.py `drop_mult` is the numpy mirror (bit-exact integer arithmetic).
+// The test suite carries a numpy mirror of this file (bit-exact integer arithmetic) to rebuild the masks on the CPU.
 #pragma once
 #include <stdint.h>
 
