@@ -398,36 +398,22 @@ struct AttnBwdArgs {
   DropSpec drop;   // attention-probability dropout (:175): element ((b*Hq + h)*N + i)*N + j
 };
 
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t ld, int r0, int N,
-                                           unsigned short (*dst)[AP], unsigned short (*dstT)[AP], int tid) {
-  // 64 rows x 64 bf16 (row r0 + r of `src`, rows >= N read as zero) -> dst[r][d] and optionally dstT[d][r]
+// 64 x 64 bf16 tile staging, split in a global-load half (issued one iteration ahead) and an LDS-store half.
+// rows r0 + r of `src` (rows >= nvalid read as zero), 64 contiguous columns.
+struct TileRegs { u32x4_t v[2]; };
+__device__ __forceinline__ TileRegs tile_load(const bf16_t* __restrict__ src, int64_t ld, int r0, int nvalid, int tid) {
+  TileRegs t;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int r = pass * 32 + (tid >> 3), ch = tid & 7;
-    u32x4_t v = {0u, 0u, 0u, 0u};
-    if (r0 + r < N) v = *(const u32x4_t*)(src + (int64_t)(r0 + r) * ld + ch * 8);
-    *(u32x4_t*)&dst[r][ch * 8] = v;
-    if (dstT) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        dstT[ch * 8 + 2 * i][r] = (unsigned short)(v[i] & 0xffffu);
-        dstT[ch * 8 + 2 * i + 1][r] = (unsigned short)(v[i] >> 16);
-      }
-    }
+    t.v[pass] = u32x4_t{0u, 0u, 0u, 0u};
+    if (r0 + r < nvalid) t.v[pass] = *(const u32x4_t*)(src + (int64_t)(r0 + r) * ld + ch * 8);
   }
+  return t;
 }
-// V^T [64 d][npad keys] (global) -> dst[j][d] for keys j0 .. j0+63 (always inside npad; padding keys are zero)
-__device__ __forceinline__ void stage_vt(const bf16_t* __restrict__ vt, int npad, int j0, unsigned short (*dst)[AP], int tid) {
-  const int d = tid >> 2, jc = (tid & 3) * 16;
-  const u32x4_t a = *(const u32x4_t*)(vt + (int64_t)d * npad + j0 + jc);
-  const u32x4_t b = *(const u32x4_t*)(vt + (int64_t)d * npad + j0 + jc + 8);
+__device__ __forceinline__ void tile_store(const TileRegs& t, unsigned short (*dst)[AP], int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    dst[jc + 2 * i][d] = (unsigned short)(a[i] & 0xffffu);
-    dst[jc + 2 * i + 1][d] = (unsigned short)(a[i] >> 16);
-    dst[jc + 8 + 2 * i][d] = (unsigned short)(b[i] & 0xffffu);
-    dst[jc + 8 + 2 * i + 1][d] = (unsigned short)(b[i] >> 16);
-  }
+  for (int pass = 0; pass < 2; ++pass) *(u32x4_t*)&dst[pass * 32 + (tid >> 3)][(tid & 7) * 8] = t.v[pass];
 }
 // acc[nt] (16 x 16 tile nt of a 16 x 64 strip) += X[xr0 + 0..15][0..63] * Y[16 nt + 0..15][0..63]^T
 __device__ __forceinline__ void strip_mma(unsigned short (*X)[AP], int xr0, unsigned short (*Y)[AP], f32x4_t* acc, int lane) {
@@ -435,6 +421,43 @@ __device__ __forceinline__ void strip_mma(unsigned short (*X)[AP], int xr0, unsi
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const bf16x8_t a = *(const bf16x8_t*)&X[xr0 + fr][ks * 32 + fg * 8];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const bf16x8_t bb = *(const bf16x8_t*)&Y[nt * 16 + fr][ks * 32 + fg * 8];
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nt], 0, 0, 0);
+    }
+  }
+}
+// Operand fragment of a TRANSPOSED image: element j of lane (fg, fr) = img[k0 + 8 fg + j][c0 + fr], j = 0..7, by two
+// ds_read_b64_tr_b16 (each hands a 16-lane group a 4-row x 16-column block column-major; lane 4q+p supplies the
+// address of row q, columns 4p..4p+3).  Needs all 64 lanes active.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8_t tr_frag(unsigned short (*img)[AP], int k0, int c0, int lane) {
+  const int fr = lane & 15, fg = lane >> 4, q = fr >> 2, pp = fr & 3;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)&img[k0 + 8 * fg + q][c0 + 4 * pp]);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)&img[k0 + 8 * fg + 4 + q][c0 + 4 * pp]);
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, both);
+}
+// acc[nt] += X[xr0 + m][k] * Yt[k][16 nt + n]      (second operand stored k-major: rows k, columns n)
+__device__ __forceinline__ void strip_mma_tr(unsigned short (*X)[AP], int xr0, unsigned short (*Yt)[AP], f32x4_t* acc, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8_t a = *(const bf16x8_t*)&X[xr0 + fr][ks * 32 + fg * 8];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, tr_frag(Yt, ks * 32, nt * 16, lane), acc[nt], 0, 0, 0);
+  }
+}
+// acc[nt] += Xt[k][xc0 + m] * Y[16 nt + n][k]      (first operand stored k-major)
+__device__ __forceinline__ void strip_mma_trA(unsigned short (*Xt)[AP], int xc0, unsigned short (*Y)[AP], f32x4_t* acc, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8_t a = tr_frag(Xt, ks * 32, xc0, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const bf16x8_t bb = *(const bf16x8_t*)&Y[nt * 16 + fr][ks * 32 + fg * 8];
@@ -464,29 +487,32 @@ __device__ __forceinline__ void store_strip(const f32x4_t* acc, bf16_t* __restri
 }
 
 __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem_dkv[];   // 8 images of [64][AP]
-  typedef unsigned short (*img_t)[AP];
-  img_t sK = (img_t)(smem_dkv + 0 * 64 * AP), sV = (img_t)(smem_dkv + 1 * 64 * AP), sQ = (img_t)(smem_dkv + 2 * 64 * AP),
-        sDO = (img_t)(smem_dkv + 3 * 64 * AP), sQT = (img_t)(smem_dkv + 4 * 64 * AP), sDOT = (img_t)(smem_dkv + 5 * 64 * AP),
-        sPT = (img_t)(smem_dkv + 6 * 64 * AP), sDST = (img_t)(smem_dkv + 7 * 64 * AP);
+  // K [j][d], V^T [d][j] (as stored), Q [i][d], dO [i][d] row-major; P^T, dS^T [j][i].  The products that contract over
+  // the ROW index of an image (dP over d of V^T, dV / dK over i of dO / Q) read it with ds_read_b64_tr_b16.
+  __shared__ __attribute__((aligned(16))) unsigned short sK[64][AP], sVt[64][AP], sQ[64][AP], sDO[64][AP], sPT[64][AP],
+      sDST[64][AP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int jb = blockIdx.x, g = blockIdx.y, b = blockIdx.z, N = p.N, G = p.Hq / p.Hkv;
   const int j0 = jb * 64;
-  stage_rows(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, sK, nullptr, tid);
-  stage_vt(p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad, p.npad, j0, sV, tid);
+  tile_store(tile_load(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, tid), sK, tid);
+  tile_store(tile_load(p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad + j0, p.npad, 0, 64, tid), sVt, tid);
   f32x4_t dk[4], dv[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) dk[nt] = dv[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int nib = (N + 63) / 64;
-  for (int hh = 0; hh < G; ++hh) {
-    const int h = g * G + hh;
-    const float* lse = p.lse + ((int64_t)b * p.Hq + h) * N;
-    const float* dl = p.delta + ((int64_t)b * p.Hq + h) * N;
-    for (int ib = 0; ib < nib; ++ib) {
+  const int nib = (N + 63) / 64, niter = G * nib;
+  const bf16_t* qb = p.q + (int64_t)b * N * p.ldq;
+  const bf16_t* dob = p.dout + (int64_t)b * N * p.ldq;
+  TileRegs rq = tile_load(qb + (g * G) * 64, p.ldq, 0, N, tid), rdo = tile_load(dob + (g * G) * 64, p.ldq, 0, N, tid);
+  for (int it = 0; it < niter; ++it) {
+    const int hh = it / nib, ib = it - hh * nib;
+    {
+      const int h = g * G + hh;
+      const float* lse = p.lse + ((int64_t)b * p.Hq + h) * N;
+      const float* dl = p.delta + ((int64_t)b * p.Hq + h) * N;
       const int i0 = ib * 64;
-      __syncthreads();   // previous iteration's LDS reads are done (also orders the K/V staging before first use)
-      stage_rows(p.q + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sQ, sQT, tid);
-      stage_rows(p.dout + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sDO, sDOT, tid);
+      __syncthreads();   // previous iteration's LDS reads are done (also orders the K / V^T staging before first use)
+      tile_store(rq, sQ, tid);
+      tile_store(rdo, sDO, tid);
       float l2[4], de[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -495,11 +521,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
         de[r] = i < N ? dl[i] : 0.f;
       }
       __syncthreads();
+      if (it + 1 < niter) {   // next (head, query block): global loads fly under this iteration's MFMAs
+        const int hn = (it + 1) / nib, ibn = (it + 1) - hn * nib;
+        rq = tile_load(qb + (g * G + hn) * 64, p.ldq, ibn * 64, N, tid);
+        rdo = tile_load(dob + (g * G + hn) * 64, p.ldq, ibn * 64, N, tid);
+      }
       f32x4_t sacc[4], pacc[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) sacc[nt] = pacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      strip_mma(sQ, wave * 16, sK, sacc, lane);    // S[i][j]
-      strip_mma(sDO, wave * 16, sV, pacc, lane);   // dP[i][j]
+      strip_mma(sQ, wave * 16, sK, sacc, lane);        // S[i][j]  = sum_d Q[i][d] K[j][d]
+      strip_mma_tr(sDO, wave * 16, sVt, pacc, lane);   // dP[i][j] = sum_d dO[i][d] V^T[d][j]
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         float pr[4], ds[4];
@@ -526,8 +557,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
         *(u32x2_t*)&sDST[nt * 16 + fr][wave * 16 + fg * 4] = d;   // dS^T[j][i]
       }
       __syncthreads();
-      strip_mma(sPT, wave * 16, sDOT, dv, lane);   // dV[j][d] += sum_i P^T[j][i] dO^T[d][i]
-      strip_mma(sDST, wave * 16, sQT, dk, lane);   // dK[j][d] += sum_i dS^T[j][i] Q^T[d][i]
+      strip_mma_tr(sPT, wave * 16, sDO, dv, lane);   // dV[j][d] += sum_i P^T[j][i] dO[i][d]
+      strip_mma_tr(sDST, wave * 16, sQ, dk, lane);   // dK[j][d] += sum_i dS^T[j][i] Q[i][d]
     }
   }
   const int nrows = min(16, N - (j0 + wave * 16));
@@ -537,13 +568,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
 }
 
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned short sQ[64][AP], sDO[64][AP], sK[64][AP], sV[64][AP], sKT[64][AP],
-      sDS[64][AP];
+  __shared__ __attribute__((aligned(16))) unsigned short sQ[64][AP], sDO[64][AP], sK[64][AP], sVt[64][AP], sDS[64][AP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int ib = blockIdx.x, h = blockIdx.y, b = blockIdx.z, N = p.N, g = h / (p.Hq / p.Hkv);
   const int i0 = ib * 64;
-  stage_rows(p.q + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sQ, nullptr, tid);
-  stage_rows(p.dout + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, sDO, nullptr, tid);
+  tile_store(tile_load(p.q + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, tid), sQ, tid);
+  tile_store(tile_load(p.dout + (int64_t)b * N * p.ldq + h * 64, p.ldq, i0, N, tid), sDO, tid);
   const float* lse = p.lse + ((int64_t)b * p.Hq + h) * N;
   const float* dl = p.delta + ((int64_t)b * p.Hq + h) * N;
   float l2[4], de[4];   // per query column i = i0 + 16 nt + fr of the transposed tiles
@@ -557,17 +587,24 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) dq[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int njb = (N + 63) / 64;
+  const bf16_t* kb = p.k + (int64_t)b * N * p.ldk + g * 64;
+  const bf16_t* vb = p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad;
+  TileRegs rk = tile_load(kb, p.ldk, 0, N, tid), rv = tile_load(vb, p.npad, 0, 64, tid);
   for (int jb = 0; jb < njb; ++jb) {
     const int j0 = jb * 64;
     __syncthreads();
-    stage_rows(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, sK, sKT, tid);
-    stage_vt(p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad, p.npad, j0, sV, tid);
+    tile_store(rk, sK, tid);
+    tile_store(rv, sVt, tid);
     __syncthreads();
+    if (jb + 1 < njb) {
+      rk = tile_load(kb, p.ldk, j0 + 64, N, tid);
+      rv = tile_load(vb + j0 + 64, p.npad, 0, 64, tid);
+    }
     f32x4_t sacc[4], pacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) sacc[nt] = pacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    strip_mma(sK, wave * 16, sQ, sacc, lane);    // S^T[j][i]
-    strip_mma(sV, wave * 16, sDO, pacc, lane);   // dP^T[j][i]
+    strip_mma(sK, wave * 16, sQ, sacc, lane);          // S^T[j][i]  = sum_d K[j][d] Q[i][d]
+    strip_mma_trA(sVt, wave * 16, sDO, pacc, lane);    // dP^T[j][i] = sum_d V^T[d][j] dO[i][d]
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       float ds[4];
@@ -587,7 +624,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
       *(u32x2_t*)&sDS[nt * 16 + fr][wave * 16 + fg * 4] = d;   // dS[i][j]
     }
     __syncthreads();
-    strip_mma(sDS, wave * 16, sKT, dq, lane);   // dQ[i][d] += sum_j dS[i][j] K^T[d][j]
+    strip_mma_tr(sDS, wave * 16, sK, dq, lane);   // dQ[i][d] += sum_j dS[i][j] K[j][d]
   }
   const int nrows = min(16, N - (i0 + wave * 16));
   store_strip(dq, p.dqkv + (int64_t)b * N * p.ldg + h * 64, p.ldg, i0 + wave * 16, nrows, i0 + wave * 16, p.rope_cos,
@@ -628,10 +665,7 @@ hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* 
   const int64_t nd = (int64_t)B * N * Hq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, o, dout, (int64_t)a.D, delta, B, N, Hq);
   const int nb = (N + 63) / 64;
-  constexpr int dkv_lds = 8 * 64 * AP * 2;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds);
-  if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, Hkv, B), dim3(256), dkv_lds, s, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, Hkv, B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb, Hq, B), dim3(256), 0, s, a);
   return hipGetLastError();
 }
