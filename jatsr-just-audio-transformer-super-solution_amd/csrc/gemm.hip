@@ -104,7 +104,14 @@ __device__ __forceinline__ void fold_emit(const GemmArgs& p, char* slot, float4 
 // PIPE 6 adds 4 DMA-only waves (one per SIMD) to the 8 MFMA waves: 768 threads, three waves per SIMD.
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
 __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
-    gemm_bf16_kernel(const GemmArgs p) {
+    gemm_bf16_kernel(const GemmArgs p_in) {
+  GemmArgs p = p_in;
+  if (p.ksplit > 1) {   // split-K slice of this block (uniform): shift the operands along K and the output to its partial
+    const int z = blockIdx.y;
+    p.A += (int64_t)z * p.K;
+    p.W += (int64_t)z * p.K;
+    p.out = (float*)p.out + (int64_t)z * p.split_stride;
+  }
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 64;
   constexpr int NW = WM * WN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -928,7 +935,8 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   if (a.N % BN != 0 || a.K % 64 != 0 || a.M <= 0) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64), LDS, s, a);
+  if (a.ksplit > 1 && EPI != EPI_F32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit > 1 ? a.ksplit : 1), dim3((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64), LDS, s, a);
   return hipGetLastError();
 }
 

@@ -286,7 +286,7 @@ static GemmProf g_prof;
 // decides is how the tile count quantises onto 256 CUs (one 8-wave block or two 4-wave blocks per CU) and how
 // many bytes are staged per MFMA: 256x160 with DMA waves (variant 25; 224 tiles at M=7168, N=1280: one round) >
 // 128x160 > 256x256 > 128x128.
-static int pick_variant(int M, int N) {
+static int pick_variant(int M, int N, int nbatch = 1) {
   // score = in-tile efficiency factor x tile-quantisation efficiency on the slots the variant occupies
   // (256 CUs x 1 eight/twelve-wave block, or x 2 four-wave blocks); factors calibrated on the measured block GEMMs
   // at M = 7168 and M = 3584 (profiles/r01/gemm_variants_*.log).  Multi-round 1-block-per-CU variants pay 15 %:
@@ -300,7 +300,7 @@ static int pick_variant(int M, int N) {
   double best_score = -1.0;
   for (const Cand& c : cands) {
     if (N % c.bn != 0) continue;
-    const long t = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+    const long t = (long)((M + c.bm - 1) / c.bm) * (N / c.bn) * nbatch;
     const long rounds = (t + c.slots - 1) / c.slots;
     double score = c.f * (double)t / (double)(rounds * c.slots);
     if (c.slots == 256 && rounds > 1) score *= 0.85;
@@ -315,7 +315,8 @@ int jat_gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const b
              int K, int epi, GemmArgs extra, hipStream_t s) {
   GemmArgs a = extra;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
-  int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N);
+  if (a.ksplit > 1) a.K = K / a.ksplit;   // per-slice depth; the kernel shifts A / W / out by blockIdx.y
+  int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N, a.ksplit > 1 ? a.ksplit : 1);
   if ((a.fold_out || a.rs_part) && !gemm_variant_coalesced(variant)) variant = 20;  // folding lives in the CE epilogues
   if (N % kTileN(variant) != 0) variant = 20;  // 128 x 128, always valid
   if (a.fold_out) { a.fold_np = N / gemm_variant_wave_n(variant); m->last_fold_np = a.fold_np; }

@@ -58,6 +58,11 @@ struct GemmArgs {
   const float* dual_add;
   int dual_rows;
   unsigned long long* dbg_out;  // profiling aid (tools/gemm_timeline.py): per-wave cycle sums of the PIPE 6 slot phases
+  // split-K (EPI_F32 only; the dW GEMMs of the training step whose M x N is too small to fill 256 CUs): grid.y = ksplit
+  // blocks each contract K columns starting at blockIdx.y * K and write their partial to out + blockIdx.y * split_stride
+  // (fp32 elements); the caller sums the partials in fixed order (launch_sum_partials).  0 / 1: off.
+  int ksplit;
+  int64_t split_stride;
 };
 
 // variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)
@@ -117,6 +122,7 @@ hipError_t launch_crossfade_pair(const float* prev, int Tp, const float* cur, in
                                  float* out, int rows, hipStream_t s);
 
 // ---- training step (train.hip): backward, loss, optimiser, data preparation -------------------------------------------
+hipError_t launch_sum_partials(const float* part, int nsplit, int64_t stride, float* out, int64_t n, hipStream_t s);
 hipError_t launch_transpose_bf16(const bf16_t* in, int64_t ld_in, int M, int C, bf16_t* out, int Mpad, hipStream_t s);
 hipError_t launch_rowsum_bf16(const bf16_t* x, int64_t ld, int R, int n, float* out, hipStream_t s);
 hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, DropSpec drop, hipStream_t s);

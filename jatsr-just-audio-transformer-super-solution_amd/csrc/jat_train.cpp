@@ -53,6 +53,8 @@ struct jat_trainer {
   CopyJob* copy_jobs = nullptr;        // device table: fp32 master slices -> the model's fp32 operand tensors
   int n_copy_jobs = 0;
   float* dw_part = nullptr;
+  float* dw_split = nullptr;           // split-K partials of the small dW GEMMs
+  int64_t split4_area = 0, split2_area = 0;
 };
 
 namespace {
@@ -103,9 +105,19 @@ int repack(jat_trainer* tr, hipStream_t s) {
 int weight_grad(jat_trainer* tr, const bf16_t* dY, int out, const bf16_t* X, int in, float* dW, float* db, hipStream_t s) {
   KCHK(launch_transpose_bf16(dY, out, tr->M, out, tr->tA, tr->Mpad, s));
   KCHK(launch_transpose_bf16(X, in, tr->M, in, tr->tB, tr->Mpad, s));
+  // M x N tiles of a small weight do not fill 256 CUs while K = all tokens is long: split K, sum the partials in order
+  const int64_t area = (int64_t)out * in;
+  const int split = area <= tr->split4_area ? 4 : (area <= tr->split2_area ? 2 : 1);
   GemmArgs e{};
-  e.out = dW; e.ldo = in; e.ntok = out;
-  JCHK(jat_gemm(tr->m, G_OTHER, tr->tA, tr->Mpad, tr->tB, tr->Mpad, out, in, tr->Mpad, EPI_F32, e, s));
+  e.ldo = in; e.ntok = out;
+  if (split > 1) {
+    e.out = tr->dw_split; e.ksplit = split; e.split_stride = area;
+    JCHK(jat_gemm(tr->m, G_OTHER, tr->tA, tr->Mpad, tr->tB, tr->Mpad, out, in, tr->Mpad, EPI_F32, e, s));
+    KCHK(launch_sum_partials(tr->dw_split, split, area, dW, area, s));
+  } else {
+    e.out = dW;
+    JCHK(jat_gemm(tr->m, G_OTHER, tr->tA, tr->Mpad, tr->tB, tr->Mpad, out, in, tr->Mpad, EPI_F32, e, s));
+  }
   if (db) KCHK(launch_rowsum_bf16(tr->tA, tr->Mpad, out, tr->Mpad, db, s));
   return JAT_OK;
 }
@@ -274,7 +286,8 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
   hipStream_t s = (hipStream_t)stream;
   jat_trainer* tr = new jat_trainer();
   tr->m = m; tr->B = B; tr->T = T; tr->ntok = ntok; tr->M = B * ntok;
-  tr->Mpad = (int)align_up((size_t)tr->M, 64); tr->npad = (int)align_up((size_t)ntok, 64);
+  tr->Mpad = (int)align_up((size_t)tr->M, 512);   // K of the dW GEMMs: divisible by 64 * (split-K factor <= 8)
+  tr->npad = (int)align_up((size_t)ntok, 64);
   tr->P = params_flat; tr->G = grads_flat; tr->m1 = exp_avg; tr->m2 = exp_avg_sq; tr->total = total;
   tr->rms = m->cfg.norm_mode == JAT_NORM_RMS_W;
   tr->p_drop.assign(m->depth, 0.f);
@@ -369,6 +382,10 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
       tr->small_part = (float*)take(slabs * B * D * 4);
     }
     tr->dw_part = (float*)take((size_t)B * D * 4);
+    tr->split4_area = (int64_t)Nqkv * D;            // q/k/v, out_proj, patch-embed proj.2: 4 slices
+    tr->split2_area = (int64_t)m->Fout * D;         // final Linear: 2 slices; the MLP weights fill the chip unsplit
+    if (tr->split2_area < tr->split4_area) tr->split2_area = tr->split4_area;
+    tr->dw_split = (float*)take((size_t)std::max(4 * tr->split4_area, 2 * tr->split2_area) * 4);
     tr->copy_jobs = (CopyJob*)take((size_t)(8 + 5 * depth + 2) * sizeof(CopyJob));
     tr->dy = (bf16_t*)take(MD2); tr->dh = (bf16_t*)take((size_t)M * std::max(mlp, bott) * 2);
     tr->dxn = (bf16_t*)take(MD2); tr->dao = (bf16_t*)take(MD2); tr->dqkv = (bf16_t*)take((size_t)M * Nqkv * 2);

@@ -36,37 +36,58 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 }
 
 // ---- bf16 transpose: out[c][m] = in[m][c], m >= M zero-filled up to Mpad (the K dimension of a dW GEMM) ----------
-// 64 x 64 tiles through LDS; reads and writes are 128-B runs.
+// 64 x 64 tiles: 16-B global loads -> row-major LDS image (144-B pitch) -> ds_read_b64_tr_b16 hands every lane 8
+// consecutive m of one output row -> 16-B global stores.
 __global__ void __launch_bounds__(256) transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int M, int C,
                                                              bf16_t* __restrict__ out, int Mpad) {
-  __shared__ unsigned short tile[64][66];
+  __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
   const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int r = pass * 32 + (tid >> 3), ch = tid & 7;
     u32x4_t v = {0u, 0u, 0u, 0u};
     if (m0 + r < M) v = *(const u32x4_t*)(in + (int64_t)(m0 + r) * ld_in + c0 + ch * 8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      tile[r][ch * 8 + 2 * i] = (unsigned short)(v[i] & 0xffffu);
-      tile[r][ch * 8 + 2 * i + 1] = (unsigned short)(v[i] >> 16);
-    }
+    *(u32x4_t*)&tile[r][ch * 8] = v;
   }
   __syncthreads();
+  // wave w owns output rows c0 + 16 w + fr; lane group fg owns m = 32 ks + 8 fg .. + 7
+  const int q = fr >> 2, pp = fr & 3;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int c = pass * 32 + (tid >> 3), ch = tid & 7;   // output row c, 8 consecutive m
+  for (int ks = 0; ks < 2; ++ks) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)&tile[ks * 32 + 8 * fg + q][wave * 16 + 4 * pp]);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)&tile[ks * 32 + 8 * fg + 4 + q][wave * 16 + 4 * pp]);
     u32x4_t v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      v[i] = (unsigned)tile[ch * 8 + 2 * i][c] | ((unsigned)tile[ch * 8 + 2 * i + 1][c] << 16);
-    if (m0 + ch * 8 < Mpad) *(u32x4_t*)(out + (int64_t)(c0 + c) * Mpad + m0 + ch * 8) = v;
+    v[0] = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    v[1] = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    v[2] = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    v[3] = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    *(u32x4_t*)(out + (int64_t)(c0 + wave * 16 + fr) * Mpad + m0 + ks * 32 + 8 * fg) = v;   // Mpad % 64 == 0: in range
   }
 }
 hipError_t launch_transpose_bf16(const bf16_t* in, int64_t ld_in, int M, int C, bf16_t* out, int Mpad, hipStream_t s) {
   if (C % 64 != 0 || Mpad % 64 != 0 || Mpad < M) return hipErrorInvalidValue;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3(Mpad / 64, C / 64), dim3(256), 0, s, in, ld_in, M, C, out, Mpad);
+  return hipGetLastError();
+}
+
+// out[i] = sum_z part[z * stride + i]   (split-K partials of a dW GEMM, fixed order)
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ part, int nsplit, int64_t stride,
+                                                           float* __restrict__ out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4_t acc = *(const f32x4_t*)(part + i * 4);
+  for (int z = 1; z < nsplit; ++z) {
+    const f32x4_t v = *(const f32x4_t*)(part + (int64_t)z * stride + i * 4);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  *(f32x4_t*)(out + i * 4) = acc;
+}
+hipError_t launch_sum_partials(const float* part, int nsplit, int64_t stride, float* out, int64_t n, hipStream_t s) {
+  if (n % 4 != 0 || stride % 4 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part, nsplit, stride, out, n / 4);
   return hipGetLastError();
 }
 
