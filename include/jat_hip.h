@@ -132,6 +132,16 @@ void jat_trainer_destroy(jat_trainer* tr);
 /* Per-layer rates (host arrays [depth]): dropout[l] = the block's nn.Dropout p (jat_audiosr_v3.py:262,269,271),
  * drop_path[l] = linspace(0, drop_path_rate, depth)[l] (:372-377).  Default: all zero. */
 int jat_trainer_set_regularisers(jat_trainer* tr, const float* dropout, const float* drop_path);
+/* Loss of the v3mod2 trainer (train_ddp_v3mod2.py:53-321,889-896):
+ *   loss = mse + latent_weight * (freq_weight * FrequencyDomainLatentLoss + ms_weight * MultiScaleLatentLoss
+ *                                 + consistency_weight * HybridConsistencyLoss(pred, clean LR latent))
+ * with the reference's defaults 0.3 / 0.5 / 0.5 / 0.1 and band ratios 0.3 / 0.30 / 0.36 (TrainConfig :362-372); fp32 rFFT
+ * over T as in the reference (:90-95).  latent_weight == 0 (the default) is the MSE-only loss of train_ddp_v3m2.py:585. */
+int jat_trainer_set_latent_loss(jat_trainer* tr, double latent_weight, double freq_weight, double ms_weight,
+                                double consistency_weight, double low_freq_phase_ratio, double strict_cutoff,
+                                double soft_cutoff);
+/* out6 (device): {total, mse, freq, ms, consistency, weighted latent sum} of the latest jat_trainer_fwd_bwd. */
+int jat_trainer_loss_terms(jat_trainer* tr, float* out6, void* stream);
 int jat_trainer_workspace_bytes(const jat_trainer* tr, size_t* out);
 /* hr_norm, noise, z_t: [B,C,T]; cond [B,Cc,T] is modified in place: cond = (cond + cond_noise * ratio *
  * (adaptive ? clamp(std(cond), 0.5, 2) : 1)) * keep[b]   (cond_noise / keep may be NULL); t [B]. */
@@ -139,9 +149,11 @@ int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float* cond, cons
                         const float* cond_noise, float cond_noise_ratio, int32_t adaptive, const float* keep,
                         const float* t, float* z_t, void* stream);
 /* Overwrites grads_flat with d(loss * loss_scale)/d(param); loss_out (device, 1 float, nullable) = unscaled loss;
- * x_pred_out (device [B,C,T], nullable) = the prediction. */
+ * x_pred_out (device [B,C,T], nullable) = the prediction.  cond_clean [B,C,T]: the normalised LR latent before the
+ * condition noise (lr_norm_original, train_ddp_v3mod2.py:861), read only by the consistency loss (may be NULL otherwise). */
 int jat_trainer_fwd_bwd(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond, const float* target,
-                        float loss_scale, uint64_t rng_seed, float* loss_out, float* x_pred_out, void* stream);
+                        const float* cond_clean, float loss_scale, uint64_t rng_seed, float* loss_out, float* x_pred_out,
+                        void* stream);
 /* grad_norm_out (device, 1 float, nullable) = L2 norm of the loss-SCALED gradients (divide by loss_scale).  A
  * non-finite norm leaves parameters and moments untouched (GradScaler.step).  `step` is 1-based (bias correction). */
 int jat_trainer_optim(jat_trainer* tr, float lr, float beta1, float beta2, float eps, float weight_decay,
@@ -162,6 +174,13 @@ int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* C,
 /* GQA attention on bf16 q[M,Hq*64], k[M,Hkv*64], vt[B,Hkv,64,Npad] -> o[M,Hq*64]; softmax(q k^T / 8) v. */
 int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t B,
                     int32_t N, int32_t Hq, int32_t Hkv, int32_t Npad, void* stream);
+/* The v3mod2 loss (see jat_trainer_set_latent_loss) on pred / target / clean-LR tensors [rows, T]: dpred = d(total *
+ * loss_scale)/d pred, out6 = {total, mse, freq, ms, consistency, weighted latent sum}; work: T*8 (rounded up to 256)
+ * + rows*32 bytes of device scratch. */
+int jat_k_latent_loss(const float* pred, const float* target, const float* lr, float* dpred, float* out6,
+                      int32_t rows, int32_t T, double latent_weight, double freq_weight, double ms_weight,
+                      double consistency_weight, double low_freq_phase_ratio, double strict_cutoff, double soft_cutoff,
+                      float loss_scale, void* work, size_t work_bytes, void* stream);
 /* fp32 -> bf16 (round-to-nearest-even) */
 int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 

@@ -48,13 +48,16 @@ SIGNATURES = {
     "jat_k_gemm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _I64, _I32, _I32, _VP]),
     "jat_k_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "jat_k_cast_bf16": (C.c_int, [_VP, _VP, _I64, _VP]),
+    "jat_k_latent_loss": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32] + [C.c_double] * 7 + [_F32, _VP, _SZ, _VP]),
     "jat_trainer_create": (C.c_int, [_VP, C.POINTER(JatTensorRef), _I32, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP,
                                      C.POINTER(_VP)]),
     "jat_trainer_destroy": (None, [_VP]),
     "jat_trainer_workspace_bytes": (C.c_int, [_VP, C.POINTER(_SZ)]),
     "jat_trainer_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F32, _I32, _VP, _VP, _VP, _VP]),
     "jat_trainer_set_regularisers": (C.c_int, [_VP, C.POINTER(_F32), C.POINTER(_F32)]),
-    "jat_trainer_fwd_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F32, C.c_uint64, _VP, _VP, _VP]),
+    "jat_trainer_set_latent_loss": (C.c_int, [_VP] + [C.c_double] * 7),
+    "jat_trainer_loss_terms": (C.c_int, [_VP, _VP, _VP]),
+    "jat_trainer_fwd_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F32, C.c_uint64, _VP, _VP, _VP]),
     "jat_trainer_optim": (C.c_int, [_VP, _F32, _F32, _F32, _F32, _F32, _F32, _F32, _I32, _VP, _VP]),
     "jat_prof_gemm_site": (C.c_int, [_I32, _I32]),
     "jat_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),

@@ -142,6 +142,12 @@ hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* 
                                 int B, int N, int Hq, int Hkv, int npad, DropSpec drop, hipStream_t s);
 hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
                            float loss_scale, hipStream_t s);
+// v3mod2 loss (MSE + lw * (fw*freq + mw*ms + cw*cons)): dpred = d(loss * loss_scale)/d pred, out6 = {total, mse, freq, ms,
+// cons, fw*freq + mw*ms + cw*cons}; part: rows*8 floats; tw: [T] (cos, sin)(2 pi m / T); lr may be null when cw == 0.
+// low / strict / soft band edges (in rfft bins) are computed by the caller exactly as the reference does (int(F * ratio)).
+hipError_t launch_latent_loss(const float* pred, const float* target, const float* lr, const float2* tw, float* dpred,
+                              float* part, float* out6, int rows, int T, float lw, float fw, float mw, float cw, int low,
+                              int strict, int soft, float loss_scale, hipStream_t s);
 hipError_t launch_grad_sqsum(const float* g, int64_t n, float* part, float* norm2, hipStream_t s);
 hipError_t launch_adamw(float* p, float* g, float* m, float* v, int64_t n, const float* norm2, float inv_scale,
                         float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);

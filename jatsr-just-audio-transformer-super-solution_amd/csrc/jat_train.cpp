@@ -53,6 +53,10 @@ struct jat_trainer {
   CopyJob* copy_jobs = nullptr;        // device table: fp32 master slices -> the model's fp32 operand tensors
   int n_copy_jobs = 0;
   float* dw_part = nullptr;
+  // v3mod2 latent perceptual loss (jat_trainer_set_latent_loss); lw == 0: plain MSE (the V3 trainer)
+  double lw = 0.0, fw = 0.5, mw = 0.5, cw = 0.1, phase_ratio = 0.3, strict_cut = 0.30, soft_cut = 0.36;
+  float2* tw = nullptr;                // [T] twiddles
+  float *ll_part = nullptr, *terms = nullptr;
   float* dw_split = nullptr;           // split-K partials of the small dW GEMMs
   int64_t split4_area = 0, split2_area = 0;
 };
@@ -207,12 +211,20 @@ int forward_train(jat_trainer* tr, const float* z_t, const float* t, const float
   return JAT_OK;
 }
 
-int backward_train(jat_trainer* tr, const float* target, float loss_scale, hipStream_t s) {
+int backward_train(jat_trainer* tr, const float* target, const float* cond_clean, float loss_scale, hipStream_t s) {
   jat_model* m = tr->m;
   const int B = tr->B, T = tr->T, ntok = tr->ntok, M = tr->M, D = m->D, Nqkv = D + 2 * m->kvD, mode = m->cfg.norm_mode;
   const int64_t mstride = (int64_t)m->depth * 6 * D;
   float* G = tr->G;
-  KCHK(launch_mse_grad(tr->pred, target, tr->dpred, tr->red_part, tr->scal, (int64_t)B * m->Cin * T, loss_scale, s));
+  if (tr->lw != 0.0) {
+    const int F = T / 2 + 1;   // band edges exactly as the reference computes them: int(freq_bins * ratio) in double
+    KCHK(launch_latent_loss(tr->pred, target, cond_clean, tr->tw, tr->dpred, tr->ll_part, tr->terms, B * m->Cin, T,
+                            (float)tr->lw, (float)tr->fw, (float)tr->mw, (float)tr->cw, (int)((double)F * tr->phase_ratio),
+                            (int)((double)F * tr->strict_cut), (int)((double)F * tr->soft_cut), loss_scale, s));
+    HIPCHK(hipMemcpyAsync(tr->scal, tr->terms, 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    KCHK(launch_mse_grad(tr->pred, target, tr->dpred, tr->red_part, tr->scal, (int64_t)B * m->Cin * T, loss_scale, s));
+  }
   // final layer: Linear (unpatchify^T is a patchify of dpred) and the un-modulated norm
   KCHK(launch_patchify(tr->dpred, nullptr, tr->dyf, B, B, B, m->Cin, 0, T, ntok, s));
   JCHK(input_grad(tr, tr->dyf, m->Fout, tr->wfinalT, D, tr->dxn, s));
@@ -372,6 +384,9 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     tr->part = (float*)take((size_t)B * train_nchunk(ntok) * 3 * D * 4);
     tr->red_part = (float*)take((size_t)train_red_blocks() * 4);
     tr->scal = (float*)take(64);
+    tr->terms = (float*)take(64);
+    tr->tw = (float2*)take((size_t)T * sizeof(float2));
+    tr->ll_part = (float*)take((size_t)B * m->Cin * 8 * 4);
     tr->delta = (float*)take((size_t)B * m->Hq * ntok * 4);
     tr->dwqkv = (float*)take((size_t)Nqkv * D * 4);
     tr->dsilu = (float*)take((size_t)B * D * 4); tr->dt_emb = (float*)take((size_t)B * D * 4);
@@ -424,6 +439,18 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
       return fail(JAT_E_HIP, "copy-table upload failed");
     }
   }
+  {
+    std::vector<float2> tw(T);
+    for (int i = 0; i < T; ++i) {
+      const double th = 2.0 * M_PI * (double)i / (double)T;
+      tw[i] = float2{(float)cos(th), (float)sin(th)};
+    }
+    if (hipMemcpyAsync(tr->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      jat_trainer_destroy(tr);
+      return fail(JAT_E_HIP, "twiddle upload failed");
+    }
+  }
   rc = build_transposes(tr, s);   // the model's own copies were packed from these very tensors by jat_model_load_weights
   if (rc != JAT_OK) { jat_trainer_destroy(tr); return rc; }
   if (hipStreamSynchronize(s) != hipSuccess) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "trainer setup failed"); }
@@ -439,6 +466,25 @@ extern "C" int jat_trainer_set_regularisers(jat_trainer* tr, const float* dropou
     tr->p_drop[l] = dropout[l];
     tr->p_path[l] = drop_path[l];
   }
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_set_latent_loss(jat_trainer* tr, double latent_weight, double freq_weight, double ms_weight,
+                                           double consistency_weight, double low_freq_phase_ratio, double strict_cutoff,
+                                           double soft_cutoff) {
+  if (!tr) return fail(JAT_E_INVALID, "null argument");
+  if (!(low_freq_phase_ratio >= 0 && low_freq_phase_ratio <= 1 && strict_cutoff >= 0 && soft_cutoff >= strict_cutoff &&
+        soft_cutoff <= 1))
+    return fail(JAT_E_INVALID, "band ratios must satisfy 0 <= strict <= soft <= 1 and 0 <= phase ratio <= 1");
+  tr->lw = latent_weight; tr->fw = freq_weight; tr->mw = ms_weight; tr->cw = consistency_weight;
+  tr->phase_ratio = low_freq_phase_ratio; tr->strict_cut = strict_cutoff; tr->soft_cut = soft_cutoff;
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_loss_terms(jat_trainer* tr, float* out6, void* stream) {
+  if (!tr || !out6) return fail(JAT_E_INVALID, "null argument");
+  if (tr->lw == 0.0) return fail(JAT_E_STATE, "the latent perceptual loss is off (jat_trainer_set_latent_loss)");
+  HIPCHK(hipMemcpyAsync(out6, tr->terms, 6 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return JAT_OK;
 }
 
@@ -464,14 +510,16 @@ extern "C" int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float*
 }
 
 extern "C" int jat_trainer_fwd_bwd(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond,
-                                   const float* target, float loss_scale, uint64_t rng_seed, float* loss_out,
-                                   float* x_pred_out, void* stream) {
+                                   const float* target, const float* cond_clean, float loss_scale, uint64_t rng_seed,
+                                   float* loss_out, float* x_pred_out, void* stream) {
   if (!tr || !z_t || !t || !x_cond || !target) return fail(JAT_E_INVALID, "null argument");
+  if (tr->lw != 0.0 && tr->cw != 0.0 && !cond_clean)
+    return fail(JAT_E_INVALID, "the consistency loss needs the clean condition latent (cond_clean)");
   if (!tr->m->loaded) return fail(JAT_E_STATE, "weights not loaded");
   hipStream_t s = (hipStream_t)stream;
   tr->seed = rng_seed;
   JCHK(forward_train(tr, z_t, t, x_cond, s));
-  JCHK(backward_train(tr, target, loss_scale, s));
+  JCHK(backward_train(tr, target, cond_clean, loss_scale, s));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, tr->scal, 4, hipMemcpyDeviceToDevice, s));
   if (x_pred_out)
     HIPCHK(hipMemcpyAsync(x_pred_out, tr->pred, (size_t)tr->B * tr->m->Cin * tr->T * 4, hipMemcpyDeviceToDevice, s));
@@ -488,4 +536,29 @@ extern "C" int jat_trainer_optim(jat_trainer* tr, float lr, float beta1, float b
                     eps, weight_decay, step, s));
   if (grad_norm_out) HIPCHK(hipMemcpyAsync(grad_norm_out, tr->scal + 3, 4, hipMemcpyDeviceToDevice, s));
   return repack(tr, s);
+}
+
+// per-kernel entry point (unit parity): the v3mod2 loss on [rows, T] tensors; `work` holds T*8 + rows*32 bytes
+extern "C" int jat_k_latent_loss(const float* pred, const float* target, const float* lr, float* dpred, float* out6,
+                                 int32_t rows, int32_t T, double latent_weight, double freq_weight, double ms_weight,
+                                 double consistency_weight, double low_freq_phase_ratio, double strict_cutoff,
+                                 double soft_cutoff, float loss_scale, void* work, size_t work_bytes, void* stream) {
+  if (!pred || !target || !dpred || !out6 || !work || rows <= 0 || T <= 0) return fail(JAT_E_INVALID, "bad argument");
+  const size_t need = align_up((size_t)T * sizeof(float2), 256) + (size_t)rows * 8 * 4;
+  if (work_bytes < need) return fail(JAT_E_STATE, "work buffer too small: %zu < %zu bytes", work_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  float2* tw = (float2*)work;
+  float* part = (float*)((char*)work + align_up((size_t)T * sizeof(float2), 256));
+  std::vector<float2> h(T);
+  for (int i = 0; i < T; ++i) {
+    const double th = 2.0 * M_PI * (double)i / (double)T;
+    h[i] = float2{(float)cos(th), (float)sin(th)};
+  }
+  HIPCHK(hipMemcpyAsync(tw, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const int F = T / 2 + 1;
+  KCHK(launch_latent_loss(pred, target, lr, tw, dpred, part, out6, rows, T, (float)latent_weight, (float)freq_weight,
+                          (float)ms_weight, (float)consistency_weight, (int)((double)F * low_freq_phase_ratio),
+                          (int)((double)F * strict_cutoff), (int)((double)F * soft_cutoff), loss_scale, s));
+  return JAT_OK;
 }

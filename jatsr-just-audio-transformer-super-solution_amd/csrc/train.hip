@@ -1006,3 +1006,182 @@ hipError_t launch_multi_copy(const CopyJob* jobs_dev, int njobs, hipStream_t s) 
   hipLaunchKernelGGL(multi_copy_kernel, dim3(32, njobs), dim3(256), 0, s, jobs_dev);
   return hipGetLastError();
 }
+
+// ---- v3mod2 training loss: MSE + latent perceptual loss (train_ddp_v3mod2.py:53-321, 889-896) ------------------------------
+//   loss = mse + lw * (fw * freq + mw * ms + cw * cons)
+//   freq = mean|log(|P|+1e-7) - log(|H|+1e-7)| + 0.1 * mean_{k<low}|P - H|                 (:97-123)   P, H, R = rfft over T
+//   ms   = (mean|p-h| + mean|pool2(p)-pool2(h)| + mean|pool4(p)-pool4(h)|) / 3             (:158-171)  of pred, target, clean LR
+//   cons = mean_{k<strict}|P - R| + mean_{strict<=k<soft} w_k ||P| - |R||, w = linspace(1,0) (:229-262)
+// One block per (b, c) row.  T = 1378 = 2*13*53 is not FFT-friendly and the whole loss is < 2 % of the step's FLOPs, so
+// the spectra are direct fp32 DFTs against an exact twiddle table (cos, sin of 2 pi m / T, m < T, index k*n mod T kept
+// incrementally), and the gradient is the adjoint sum  dp_n = Re sum_k g_k e^{+i 2 pi k n / T}  over the rfft bins.
+// Bound: fp32 VALU (8 FMA per (k, n) pair).  Loss terms: per-row partials, finished in fixed order.
+struct LatentLossArgs {
+  const float *pred, *target, *lr;   // [rows, T]; lr = clean normalised condition (may be null when cw == 0)
+  const float2* tw;                  // [T] (cos, sin)(2 pi m / T)
+  float* dpred;                      // [rows, T]   d(total loss * gscale)/d pred
+  float* part;                       // [rows, 8] partial sums: se, logmag, low, l1, l1p2, l1p4, strict, trans
+  int rows, T, F, low, strict, soft;
+  float lw, fw, mw, cw, gscale;      // weights; gscale = loss_scale
+  float inv_n;                       // 1 / (rows * T)
+};
+__global__ void __launch_bounds__(256) latent_loss_kernel(const LatentLossArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = a.T, F = a.F, tid = threadIdx.x;
+  float* sp = sm;                 // pred row
+  float* sh = sp + T;             // target row
+  float* sr = sh + T;             // clean LR row
+  float2* stw = (float2*)(sr + T);   // twiddles
+  float2* sg = stw + T;           // spectral gradient g_k
+  float* red = (float*)(sg + F);  // [4 waves][8]
+  const int64_t row = blockIdx.x;
+  const bool use_lr = a.lr != nullptr && a.cw != 0.f;
+  for (int n = tid; n < T; n += 256) {
+    sp[n] = a.pred[row * T + n];
+    sh[n] = a.target[row * T + n];
+    sr[n] = use_lr ? a.lr[row * T + n] : 0.f;
+    stw[n] = a.tw[n];
+  }
+  __syncthreads();
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const float rows_f = (float)a.rows;
+  // mean normalisers of the spectral terms (per element); guarded against empty bands
+  const float n_log = 1.0f / (rows_f * F), n_low = a.low > 0 ? 1.0f / (rows_f * a.low) : 0.f;
+  const float n_str = a.strict > 0 ? 1.0f / (rows_f * a.strict) : 0.f;
+  const int bw = a.soft - a.strict;
+  const float n_tr = bw > 0 ? 1.0f / (rows_f * bw) : 0.f;
+  for (int k = tid; k < F; k += 256) {
+    float pa = 0.f, pb = 0.f, ha = 0.f, hb = 0.f, ra = 0.f, rb = 0.f;
+    int idx = 0;
+    for (int n = 0; n < T; ++n) {
+      const float2 w = stw[idx];          // e^{-i theta} = cos - i sin
+      const float x = sp[n], y = sh[n], z = sr[n];
+      pa += x * w.x; pb -= x * w.y;
+      ha += y * w.x; hb -= y * w.y;
+      ra += z * w.x; rb -= z * w.y;
+      idx += k; if (idx >= T) idx -= T;
+    }
+    float ga = 0.f, gb = 0.f;
+    const float pm = sqrtf(pa * pa + pb * pb), hm = sqrtf(ha * ha + hb * hb);
+    {   // log-magnitude L1
+      const float d = __logf(pm + 1e-7f) - __logf(hm + 1e-7f);
+      acc[1] += fabsf(d);
+      if (pm > 0.f && d != 0.f) {
+        const float c = a.fw * (d > 0.f ? 1.f : -1.f) / (pm + 1e-7f) * n_log / pm;
+        ga += c * pa; gb += c * pb;
+      }
+    }
+    if (k < a.low) {   // low-frequency complex L1 (weight 0.1 inside freq)
+      const float da = pa - ha, db = pb - hb, m = sqrtf(da * da + db * db);
+      acc[2] += m;
+      if (m > 0.f) { const float c = a.fw * 0.1f * n_low / m; ga += c * da; gb += c * db; }
+    }
+    if (use_lr) {
+      if (k < a.strict) {
+        const float da = pa - ra, db = pb - rb, m = sqrtf(da * da + db * db);
+        acc[6] += m;
+        if (m > 0.f) { const float c = a.cw * n_str / m; ga += c * da; gb += c * db; }
+      } else if (k < a.soft) {
+        const float wk = bw > 1 ? 1.0f - (float)(k - a.strict) / (float)(bw - 1) : 1.0f;   // torch.linspace(1, 0, bw)
+        const float rm = sqrtf(ra * ra + rb * rb), d = pm - rm;
+        acc[7] += wk * fabsf(d);
+        if (pm > 0.f && d != 0.f) { const float c = a.cw * wk * (d > 0.f ? 1.f : -1.f) * n_tr / pm; ga += c * pa; gb += c * pb; }
+      }
+    }
+    sg[k] = float2{ga, gb};
+  }
+  __syncthreads();
+  const int T2 = T / 2, T4 = T / 4;
+  const float lam = a.lw * a.gscale;
+  for (int n = tid; n < T; n += 256) {
+    // adjoint DFT: sum_k ga cos(theta) - gb sin(theta), theta = 2 pi k n / T
+    float s = 0.f;
+    int idx = 0;
+    for (int k = 0; k < F; ++k) {
+      const float2 w = stw[idx], g = sg[k];
+      s += g.x * w.x - g.y * w.y;
+      idx += n; if (idx >= T) idx -= T;
+    }
+    const float e = sp[n] - sh[n];
+    acc[0] += e * e;
+    acc[3] += fabsf(e);
+    float gt = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * a.inv_n;   // d mean|p-h|
+    if (n < 2 * T2) {
+      const int j = n >> 1;
+      const float q = 0.5f * ((sp[2 * j] - sh[2 * j]) + (sp[2 * j + 1] - sh[2 * j + 1]));
+      if ((n & 1) == 0) acc[4] += fabsf(q);
+      gt += (q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f)) * 0.5f / (rows_f * T2);
+    }
+    if (n < 4 * T4) {
+      const int j = n >> 2;
+      float q = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q += sp[4 * j + u] - sh[4 * j + u];
+      q *= 0.25f;
+      if ((n & 3) == 0) acc[5] += fabsf(q);
+      gt += (q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f)) * 0.25f / (rows_f * T4);
+    }
+    a.dpred[row * T + n] = a.gscale * 2.0f * e * a.inv_n + lam * (s + a.mw * gt * (1.0f / 3.0f));
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = wave_sum_t(acc[i]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[(tid >> 6) * 8 + i] = acc[i];
+  __syncthreads();
+  if (tid < 8) a.part[row * 8 + tid] = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
+}
+// out[0] = total, [1] = mse, [2] = freq, [3] = ms, [4] = cons, [5] = fw*freq + mw*ms + cw*cons
+__global__ void __launch_bounds__(256) latent_loss_finish_kernel(const float* __restrict__ part, const LatentLossArgs a,
+                                                                 float* __restrict__ out) {
+  __shared__ double red[8][256];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < a.rows; r += 256)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += (double)part[(int64_t)r * 8 + i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[i][threadIdx.x] = acc[i];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double rows = a.rows, T = a.T, n = rows * T;
+    const double mse = red[0][0] / n;
+    const double freq = red[1][0] / (rows * a.F) + (a.low > 0 ? 0.1 * red[2][0] / (rows * a.low) : 0.0);
+    const int T2 = a.T / 2, T4 = a.T / 4;
+    const double ms = (red[3][0] / n + (T2 > 0 ? red[4][0] / (rows * T2) : 0.0) + (T4 > 0 ? red[5][0] / (rows * T4) : 0.0)) / 3.0;
+    const int bw = a.soft - a.strict;
+    const double cons = (a.strict > 0 ? red[6][0] / (rows * a.strict) : 0.0) + (bw > 0 ? red[7][0] / (rows * bw) : 0.0);
+    const double lat = a.fw * freq + a.mw * ms + a.cw * cons;
+    out[0] = (float)(mse + a.lw * lat); out[1] = (float)mse; out[2] = (float)freq; out[3] = (float)ms;
+    out[4] = (float)cons; out[5] = (float)lat;
+  }
+}
+hipError_t launch_latent_loss(const float* pred, const float* target, const float* lr, const float2* tw, float* dpred,
+                              float* part, float* out6, int rows, int T, float lw, float fw, float mw, float cw, int low,
+                              int strict, int soft, float loss_scale, hipStream_t s) {
+  LatentLossArgs a;
+  a.pred = pred; a.target = target; a.lr = lr; a.tw = tw; a.dpred = dpred; a.part = part;
+  a.rows = rows; a.T = T; a.F = T / 2 + 1;
+  a.low = low; a.strict = strict; a.soft = soft;
+  if (low < 0 || low > a.F || strict < 0 || soft < strict || soft > a.F) return hipErrorInvalidValue;
+  a.lw = lw; a.fw = fw; a.mw = mw; a.cw = cw; a.gscale = loss_scale;
+  a.inv_n = 1.0f / ((float)rows * (float)T);
+  const size_t lds = (size_t)(3 * T) * 4 + (size_t)(T + a.F) * 8 + 32 * 4;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static size_t attr_set = 0;
+  if (lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)latent_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL(latent_loss_kernel, dim3(rows), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(latent_loss_finish_kernel, dim3(1), dim3(256), 0, s, part, a, out6);
+  return hipGetLastError();
+}

@@ -101,7 +101,12 @@ class Trainer:
 
     def __init__(self, model, batch_size, frames, lr=5e-5, weight_decay=0.1, betas=(0.9, 0.999), eps=1e-8,
                  grad_clip=1.0, cfg_dropout_prob=0.1, condition_noise_ratio=0.02, use_adaptive_noise=True,
-                 warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None):
+                 warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None,
+                 latent_loss_weight=0.0, freq_loss_weight=0.5, ms_loss_weight=0.5, consistency_weight=0.1,
+                 low_freq_phase_ratio=0.3, strict_cutoff=0.30, soft_cutoff=0.36):
+        """latent_loss_weight > 0 selects the v3mod2 trainer's loss, MSE + latent perceptual loss
+        (train_ddp_v3mod2.py:53-321,362-372,889-896; its TrainConfig uses 0.3 with the other defaults given here, no CFG
+        dropout and condition_noise_ratio 0.05); 0 is the MSE-only loss of train_ddp_v3m2.py:585."""
         L.require_gpu()
         self.model = model
         self.B, self.T = int(batch_size), int(frames)
@@ -147,6 +152,20 @@ class Trainer:
         self.mask_seed = 0x9E3779B97F4A7C15 if seed is None else int(seed)
         self.set_regularisers([getattr(b, "dropout_rate", 0.0) for b in model.blocks],
                               [getattr(b, "drop_path_rate", 0.0) for b in model.blocks])
+        self.latent_loss = dict(latent_weight=float(latent_loss_weight), freq_weight=float(freq_loss_weight),
+                                ms_weight=float(ms_loss_weight), consistency_weight=float(consistency_weight),
+                                low_freq_phase_ratio=float(low_freq_phase_ratio), strict_cutoff=float(strict_cutoff),
+                                soft_cutoff=float(soft_cutoff))
+        L.check(L.lib().jat_trainer_set_latent_loss(self.ptr, *self.latent_loss.values()))
+        self._terms = torch.zeros(6, dtype=torch.float32, device=dev)
+
+    def loss_terms(self):
+        """{total, mse, freq, ms, consistency, latent} of the latest step (the trainer's `latent_loss_dict`,
+        train_ddp_v3mod2.py:313-318); MSE-only trainers return {total}."""
+        if self.latent_loss["latent_weight"] == 0.0:
+            return dict(total=float(self._scal[0]))
+        L.check(L.lib().jat_trainer_loss_terms(self.ptr, L.ptr(self._terms), L.stream_ptr()))
+        return dict(zip(("total", "mse", "freq", "ms", "consistency", "latent"), self._terms.tolist()))
 
     def set_regularisers(self, dropout, drop_path):
         """Per-layer nn.Dropout p and DropPath rate (defaults: what the model was constructed with,
@@ -208,16 +227,20 @@ class Trainer:
                                             int(self.use_adaptive_noise), L.ptr(keep), L.ptr(t), L.ptr(z_t), L.stream_ptr()))
         return z_t, t, cond
 
-    def forward_backward(self, z_t, t, cond, target, want_pred=False, mask_seed=None):
-        """pred = model(z_t, t, cond); loss = mse_loss(pred, target); backward -> self.grads (scaled by scaler.scale).
-        mask_seed: 64-bit seed of this step's Dropout / DropPath masks (default: `step_seed()`)."""
-        for x in (z_t, cond, target):
+    def forward_backward(self, z_t, t, cond, target, want_pred=False, mask_seed=None, cond_clean=None):
+        """pred = model(z_t, t, cond); loss(pred, target[, cond_clean]); backward -> self.grads (scaled by scaler.scale).
+        mask_seed: 64-bit seed of this step's Dropout / DropPath masks (default: `step_seed()`).
+        cond_clean: the normalised LR latent before the condition noise (`lr_norm_original`, train_ddp_v3mod2.py:861),
+        needed by the consistency term of the latent perceptual loss."""
+        for x in (z_t, cond, target) + ((cond_clean,) if cond_clean is not None else ()):
             if tuple(x.shape) != (self.B, self.model.input_channels, self.T) or x.dtype != torch.float32 or not x.is_cuda:
                 raise ValueError(f"expected fp32 CUDA [{self.B}, {self.model.input_channels}, {self.T}], got "
                                  f"{tuple(x.shape)} {x.dtype} on {x.device}")
         pred = torch.empty_like(z_t) if want_pred else None
         L.check(L.lib().jat_trainer_fwd_bwd(self.ptr, L.ptr(z_t.contiguous()), L.ptr(t.contiguous()), L.ptr(cond.contiguous()),
-                                            L.ptr(target.contiguous()), float(self.scaler.scale),
+                                            L.ptr(target.contiguous()),
+                                            L.ptr(cond_clean.contiguous()) if cond_clean is not None else None,
+                                            float(self.scaler.scale),
                                             C.c_uint64(self.step_seed() if mask_seed is None else int(mask_seed)),
                                             L.ptr(self._scal),
                                             L.ptr(pred) if want_pred else None, L.stream_ptr()))
@@ -248,7 +271,7 @@ class Trainer:
         hr_norm = channel_affine(hr.to(self.device, torch.float32), hr_mean, hr_std)
         lr_norm = channel_affine(lr.to(self.device, torch.float32), lr_mean, lr_std)
         z_t, t, cond = self.prepare(hr_norm, lr_norm)
-        self.forward_backward(z_t, t, cond, hr_norm)
+        self.forward_backward(z_t, t, cond, hr_norm, cond_clean=lr_norm)
         loss, gnorm = self.optimizer_step()
         return dict(loss=loss, grad_norm=gnorm, lr=self.last_lr, step=self.global_step)
 

@@ -191,6 +191,73 @@ def dropout_case(name, cfg_name, B, T, t_list, seed, dropout=0.1, drop_path_rate
     print(f"[golden] train_{name}: loss={rec['loss64']:.6f} (dropout {dropout}, drop_path {dpr})")
 
 
+def ref_loss_classes():
+    """The four loss classes of train_ddp_v3mod2.py:53-321, taken from the file itself with `ast` (the module cannot be
+    imported: tensorboard, process group)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    src = open(os.path.join(REF, "train_ddp_v3mod2.py"), encoding="utf-8").read()
+    want = ("FrequencyDomainLatentLoss", "MultiScaleLatentLoss", "HybridConsistencyLoss", "CombinedLatentPerceptualLoss")
+    body = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name in want]
+    assert len(body) == 4
+    ns = {"torch": torch, "nn": nn, "F": F}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "train_ddp_v3mod2.py", "exec"), ns)
+    return ns["CombinedLatentPerceptualLoss"]
+
+
+def loss_case(name, B, C, T, salt=0, lw=0.3, fw=0.5, mw=0.5, cw=0.1):
+    """Value and d/d pred of  mse + lw * CombinedLatentPerceptualLoss(pred, target, lr)  (train_ddp_v3mod2.py:889-896,
+    weights :362-366) on recipe tensors; fp32 inside, as the reference forces (`.float()`, :90-91)."""
+    Loss = ref_loss_classes()
+    fn = Loss(freq_weight=fw, ms_weight=mw, consistency_weight=cw, low_freq_phase_ratio=0.3)
+    pred = torch.from_numpy(recipe.gaussian("loss_pred", (B, C, T), salt + 400)).requires_grad_(True)
+    target = torch.from_numpy(recipe.gaussian("loss_target", (B, C, T), salt + 401))
+    lr = torch.from_numpy(0.7 * recipe.gaussian("loss_target", (B, C, T), salt + 401)
+                          + 0.5 * recipe.gaussian("loss_lr", (B, C, T), salt + 402)).float()
+    mse = torch.nn.functional.mse_loss(pred, target)
+    lat, terms = fn(pred, target, lr)
+    total = mse + lw * lat
+    total.backward()
+    rec = {"total": np.float64(total.item()), "mse": np.float64(mse.item()), "freq": np.float64(terms["freq_loss"]),
+           "ms": np.float64(terms["ms_loss"]), "consistency": np.float64(terms["consistency_loss"]),
+           "latent": np.float64(terms["total_latent_loss"]), "dpred": pred.grad.numpy(),
+           "meta": json.dumps(dict(case=name, B=B, C=C, T=T, salt=salt, lw=lw, fw=fw, mw=mw, cw=cw, torch=torch.__version__))}
+    np.savez_compressed(os.path.join(GOLD, f"train_loss_{name}.npz"), **rec)
+    print(f"[golden] train_loss_{name}: total={rec['total']:.6f} mse={rec['mse']:.6f} freq={rec['freq']:.5f} "
+          f"ms={rec['ms']:.5f} cons={rec['consistency']:.5f}")
+
+
+def mod2_step_case(name, cfg_name, B, T, t_list, salt=0, strides=(7, 5), lw=0.3, fw=0.5, mw=0.5, cw=0.1):
+    """One v3mod2 step end to end: JaT_AudioSR_V2 (LayerNorm) + MSE + latent perceptual loss with the clean LR latent
+    (train_ddp_v3mod2.py:854-896), dropout = drop_path = 0, cond noise injected; gradients of every parameter (fp64
+    model, the loss classes force fp32 internally exactly as in the trainer)."""
+    Loss = ref_loss_classes()
+    fn = Loss(freq_weight=fw, ms_weight=mw, consistency_weight=cw, low_freq_phase_ratio=0.3)
+    cfg = recipe.CONFIGS[cfg_name]
+    hr, lr, noise = step_inputs(cfg, B, T, salt)
+    cnoise = 0.05 * recipe.gaussian("train_cnoise", hr.shape, salt + 303)
+    t = np.asarray(t_list, dtype=np.float32)
+    m = ref_model(cfg, "ln", salt, torch.float64)
+    hr_t, lr_t, nz, cn = (torch.from_numpy(a).double() for a in (hr, lr, noise, cnoise))
+    tt = torch.from_numpy(t).double()
+    tv = tt.view(-1, 1, 1)
+    pred = m(tv * hr_t + (1 - tv) * nz, tt, lr_t + cn)
+    mse = torch.nn.functional.mse_loss(pred, hr_t)
+    lat, terms = fn(pred, hr_t, lr_t)
+    loss = mse + lw * lat
+    loss.backward()
+    rec = {"loss64": np.float64(loss.item()), "mse": np.float64(mse.item()), "latent": np.float64(lat.item()),
+           "pred_l2": np.float64(pred.detach().norm().item())}
+    for k, p in m.named_parameters():
+        rec["g_" + k] = sub(p.grad.numpy(), strides)
+        rec["gl2_" + k] = np.float64(p.grad.norm().item())
+    rec["meta"] = json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, t=[float(v) for v in t], norm="ln", salt=salt,
+                                  lw=lw, fw=fw, mw=mw, cw=cw, full_limit=FULL_LIMIT, strides=strides,
+                                  torch=torch.__version__, names=[k for k, _ in m.named_parameters()]))
+    np.savez_compressed(os.path.join(GOLD, f"train_{name}.npz"), **rec)
+    print(f"[golden] train_{name}: loss={rec['loss64']:.6f} (mse {rec['mse']:.6f} + {lw} * latent {rec['latent']:.5f})")
+
+
 def u_shape_case():
     src = open(os.path.join(REF, "train_ddp_v3m2.py"), encoding="utf-8").read()
     fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "u_shaped_timestep_sampling"]
@@ -224,6 +291,13 @@ def main(which):
                      drop_path_rate=0.4)
         dropout_case("tiny_drop_T128", "tiny", 2, 128, [0.2, 0.9], seed=77, dropout=0.1, drop_path_rate=0.3,
                      strides=(61, 53))
+    if allc or "loss" in which:
+        loss_case("T24", 2, 32, 24)
+        loss_case("T22", 3, 32, 22, salt=1)
+        loss_case("T9", 1, 32, 9, salt=2)                 # odd T, empty / one-bin bands
+        loss_case("T1378", 1, 64, 1378, salt=3)           # the trainer's crop: 690 bins, bands at 207 / 248
+        mod2_step_case("micro_mod2_T24", "micro", 2, 24, [0.1, 0.85], salt=2)
+        mod2_step_case("tiny_mod2_T128", "tiny", 2, 128, [0.2, 0.9], salt=1, strides=(61, 53))
     if allc or "misc" in which:
         u_shape_case()
 

@@ -241,8 +241,14 @@ class TrainOracle:
         return grads
 
     # ---- the step ---------------------------------------------------------------------------------------------------
-    def loss_and_grads(self, z_t, t, cond, target, plan=None):
+    def loss_and_grads(self, z_t, t, cond, target, plan=None, latent=None, cond_clean=None):
+        """latent: None (MSE, train_ddp_v3m2.py:585) or the keyword dict of latent_loss_oracle.latent_loss (the v3mod2
+        loss, train_ddp_v3mod2.py:889-896, evaluated against the clean condition latent `cond_clean`)."""
         pred = self.forward(z_t, t, cond, plan)
+        if latent:
+            from . import latent_loss_oracle as LO
+            terms, dpred = LO.latent_loss(pred, target, cond_clean, **latent)
+            return float(terms["total"]), self.backward(dpred), pred
         diff = pred - np.asarray(target, np.float64)
         return float(np.mean(diff * diff)), self.backward(2.0 * diff / diff.size), pred
 

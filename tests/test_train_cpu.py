@@ -165,3 +165,48 @@ def test_gradient_allreduce_world2_gloo():
     for rank, w, vals in got:
         assert w == 2 and vals == [3.0 * i for i in range(8)]
     assert T.allreduce_mean_(torch.ones(4)) == 1       # no process group: identity
+
+
+def _loss_inputs(meta):
+    B, C, Tn, salt = meta["B"], meta["C"], meta["T"], meta["salt"]
+    pred = recipe.gaussian("loss_pred", (B, C, Tn), salt + 400)
+    target = recipe.gaussian("loss_target", (B, C, Tn), salt + 401)
+    lr = (0.7 * recipe.gaussian("loss_target", (B, C, Tn), salt + 401)
+          + 0.5 * recipe.gaussian("loss_lr", (B, C, Tn), salt + 402)).astype(np.float32)
+    return pred, target, lr
+
+
+@pytest.mark.parametrize("name", ["train_loss_T24", "train_loss_T22", "train_loss_T9", "train_loss_T1378"])
+def test_latent_loss_oracle_matches_reference_classes(name):
+    """MSE + latent perceptual loss of the v3mod2 trainer: the fixture ran the reference's own loss classes (taken from
+    train_ddp_v3mod2.py with `ast`) under autograd in fp32; the numpy oracle (fp64) must agree to fp32-FFT accuracy."""
+    from oracle import latent_loss_oracle as LO
+    z, meta = load_golden(name)
+    terms, dpred = LO.latent_loss(*_loss_inputs(meta), latent_weight=meta["lw"], freq_weight=meta["fw"],
+                                  ms_weight=meta["mw"], consistency_weight=meta["cw"])
+    for k in ("total", "mse", "freq", "ms", "consistency", "latent"):
+        assert abs(terms[k] - float(z[k])) <= 2e-6 * abs(float(z[k])), k
+    assert rel_l2(dpred, z["dpred"]) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["train_micro_mod2_T24", "train_tiny_mod2_T128"])
+def test_train_oracle_v3mod2_step_matches_reference(name):
+    """LayerNorm model + MSE + latent perceptual loss with the clean LR latent (train_ddp_v3mod2.py:854-896)."""
+    z, meta = load_golden(name)
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    C, B, Tn, salt = cfg["input_channels"], meta["B"], meta["T"], meta["salt"]
+    sd = recipe.make_state_dict(cfg, "ln", salt)
+    hr = recipe.gaussian("train_hr", (B, C, Tn), salt + 300).astype(np.float64)
+    lr = recipe.gaussian("train_lr", (B, C, Tn), salt + 301).astype(np.float64)
+    noise = recipe.gaussian("train_noise", (B, C, Tn), salt + 302).astype(np.float64)
+    cn = 0.05 * recipe.gaussian("train_cnoise", (B, C, Tn), salt + 303).astype(np.float64)
+    t = np.asarray(meta["t"], np.float32).astype(np.float64)
+    tv = t.reshape(B, 1, 1)
+    latent = dict(latent_weight=meta["lw"], freq_weight=meta["fw"], ms_weight=meta["mw"], consistency_weight=meta["cw"])
+    loss, grads, pred = OT.TrainOracle(cfg, sd, "ln").loss_and_grads(tv * hr + (1 - tv) * noise, t, lr + cn, hr,
+                                                                     latent=latent, cond_clean=lr)
+    assert abs(loss - float(z["loss64"])) <= 1e-6 * float(z["loss64"])
+    for k in meta["names"]:
+        ref_l2 = float(z["gl2_" + k])
+        assert abs(np.linalg.norm(grads[k]) - ref_l2) <= 2e-4 * max(ref_l2, 1e-30), k   # the reference runs its FFT terms in fp32
+        assert rel_l2(gsub(grads[k], meta), z["g_" + k]) <= 5e-4, k
