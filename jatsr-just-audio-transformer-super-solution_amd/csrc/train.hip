@@ -1025,9 +1025,11 @@ struct LatentLossArgs {
   float lw, fw, mw, cw, gscale;      // weights; gscale = loss_scale
   float inv_n;                       // 1 / (rows * T)
 };
+template <int FB, int NB>   // bins / samples per thread of the blocked DFT loops (the launcher picks the smallest cover)
 __global__ void __launch_bounds__(256) latent_loss_kernel(const LatentLossArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T = a.T, F = a.F, tid = threadIdx.x;
+  constexpr int RS = 8;    // twiddle re-seed interval (see the forward loop)
   float* sp = sm;                 // pred row
   float* sh = sp + T;             // target row
   float* sr = sh + T;             // clean LR row
@@ -1052,17 +1054,53 @@ __global__ void __launch_bounds__(256) latent_loss_kernel(const LatentLossArgs a
   const float n_str = a.strict > 0 ? 1.0f / (rows_f * a.strict) : 0.f;
   const int bw = a.soft - a.strict;
   const float n_tr = bw > 0 ? 1.0f / (rows_f * bw) : 0.f;
-  for (int k = tid; k < F; k += 256) {
-    float pa = 0.f, pb = 0.f, ha = 0.f, hb = 0.f, ra = 0.f, rb = 0.f;
-    int idx = 0;
-    for (int n = 0; n < T; ++n) {
-      const float2 w = stw[idx];          // e^{-i theta} = cos - i sin
-      const float x = sp[n], y = sh[n], z = sr[n];
-      pa += x * w.x; pb -= x * w.y;
-      ha += y * w.x; hb -= y * w.y;
-      ra += z * w.x; rb -= z * w.y;
-      idx += k; if (idx >= T) idx -= T;
+  // forward DFTs: a thread owns up to FB bins (k = tid + 256 j) and walks n once for all of them, so the three row
+  // samples are read from LDS once per n instead of once per (bin, n)
+  for (int kbase = 0; kbase < F; kbase += 256 * FB) {
+  float spa[FB], spb[FB], sha[FB], shb[FB], sra[FB], srb[FB];
+  int kk[FB], idxs[FB];
+#pragma unroll
+  for (int j = 0; j < FB; ++j) {
+    spa[j] = spb[j] = sha[j] = shb[j] = sra[j] = srb[j] = 0.f;
+    kk[j] = kbase + tid + 256 * j;
+    if (kk[j] >= F) kk[j] = 0;   // idle slot: computes bin 0 again, result unused
+    idxs[j] = 0;
+  }
+  // twiddle e^{-i theta_kn} by rotation with the bin's step e^{-i theta_k}, re-seeded from the exact table every RS
+  // samples (error growth RS * 2^-24): four FMAs instead of a bank-conflicted LDS gather per (bin, sample)
+  float ck[FB], sk[FB];
+  int step16[FB];
+#pragma unroll
+  for (int j = 0; j < FB; ++j) {
+    const float2 w = stw[kk[j]];
+    ck[j] = w.x; sk[j] = w.y;
+    step16[j] = (int)(((long long)kk[j] * RS) % T);
+  }
+  for (int nb = 0; nb < T; nb += RS) {
+    float c[FB], sn[FB];
+#pragma unroll
+    for (int j = 0; j < FB; ++j) { const float2 w = stw[idxs[j]]; c[j] = w.x; sn[j] = w.y; }
+    const int nend = min(RS, T - nb);
+    for (int u = 0; u < nend; ++u) {
+      const float x = sp[nb + u], y = sh[nb + u], zz = sr[nb + u];
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        spa[j] += x * c[j]; spb[j] -= x * sn[j];
+        sha[j] += y * c[j]; shb[j] -= y * sn[j];
+        sra[j] += zz * c[j]; srb[j] -= zz * sn[j];
+        const float cn = c[j] * ck[j] - sn[j] * sk[j];
+        sn[j] = sn[j] * ck[j] + c[j] * sk[j];
+        c[j] = cn;
+      }
     }
+#pragma unroll
+    for (int j = 0; j < FB; ++j) { idxs[j] += step16[j]; if (idxs[j] >= T) idxs[j] -= T; }
+  }
+#pragma unroll
+  for (int j = 0; j < FB; ++j) {
+    const int k = kbase + tid + 256 * j;
+    if (k >= F) continue;
+    const float pa = spa[j], pb = spb[j], ha = sha[j], hb = shb[j], ra = sra[j], rb = srb[j];
     float ga = 0.f, gb = 0.f;
     const float pm = sqrtf(pa * pa + pb * pb), hm = sqrtf(ha * ha + hb * hb);
     {   // log-magnitude L1
@@ -1092,18 +1130,52 @@ __global__ void __launch_bounds__(256) latent_loss_kernel(const LatentLossArgs a
     }
     sg[k] = float2{ga, gb};
   }
+  }
   __syncthreads();
   const int T2 = T / 2, T4 = T / 4;
   const float lam = a.lw * a.gscale;
-  for (int n = tid; n < T; n += 256) {
-    // adjoint DFT: sum_k ga cos(theta) - gb sin(theta), theta = 2 pi k n / T
-    float s = 0.f;
-    int idx = 0;
-    for (int k = 0; k < F; ++k) {
-      const float2 w = stw[idx], g = sg[k];
-      s += g.x * w.x - g.y * w.y;
-      idx += n; if (idx >= T) idx -= T;
+  for (int nbase = 0; nbase < T; nbase += 256 * NB) {
+  // adjoint DFT: s_n = sum_k ga cos(theta) - gb sin(theta), theta = 2 pi k n / T; g_k is read once per k for NB samples
+  float sv[NB];
+  int nn[NB], idn[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    sv[j] = 0.f;
+    nn[j] = nbase + tid + 256 * j;
+    if (nn[j] >= T) nn[j] = 0;
+    idn[j] = 0;
+  }
+  float cnn[NB], snn[NB];
+  int stepn[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const float2 w = stw[nn[j]];
+    cnn[j] = w.x; snn[j] = w.y;
+    stepn[j] = (int)(((long long)nn[j] * RS) % T);
+  }
+  for (int kb = 0; kb < F; kb += RS) {
+    float c[NB], sn[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const float2 w = stw[idn[j]]; c[j] = w.x; sn[j] = w.y; }
+    const int kend = min(RS, F - kb);
+    for (int u = 0; u < kend; ++u) {
+      const float2 g = sg[kb + u];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        sv[j] += g.x * c[j] - g.y * sn[j];
+        const float cn = c[j] * cnn[j] - sn[j] * snn[j];
+        sn[j] = sn[j] * cnn[j] + c[j] * snn[j];
+        c[j] = cn;
+      }
     }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { idn[j] += stepn[j]; if (idn[j] >= T) idn[j] -= T; }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = nbase + tid + 256 * j;
+    if (n >= T) continue;
+    const float s = sv[j];
     const float e = sp[n] - sh[n];
     acc[0] += e * e;
     acc[3] += fabsf(e);
@@ -1124,6 +1196,7 @@ __global__ void __launch_bounds__(256) latent_loss_kernel(const LatentLossArgs a
       gt += (q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f)) * 0.25f / (rows_f * T4);
     }
     a.dpred[row * T + n] = a.gscale * 2.0f * e * a.inv_n + lam * (s + a.mw * gt * (1.0f / 3.0f));
+  }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = wave_sum_t(acc[i]);
@@ -1175,13 +1248,22 @@ hipError_t launch_latent_loss(const float* pred, const float* target, const floa
   a.inv_n = 1.0f / ((float)rows * (float)T);
   const size_t lds = (size_t)(3 * T) * 4 + (size_t)(T + a.F) * 8 + 32 * 4;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static size_t attr_set = 0;
-  if (lds > attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)latent_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = lds;
+  const int fb = (a.F + 255) / 256, nb = (T + 255) / 256;
+#define LL_CASE(FBv, NBv)                                                                                              \
+  {                                                                                                                    \
+    static size_t attr_set = 0;                                                                                        \
+    if (lds > attr_set) {                                                                                              \
+      hipError_t e = hipFuncSetAttribute((const void*)latent_loss_kernel<FBv, NBv>,                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+      if (e != hipSuccess) return e;                                                                                   \
+      attr_set = lds;                                                                                                  \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((latent_loss_kernel<FBv, NBv>), dim3(rows), dim3(256), lds, s, a);                              \
   }
-  hipLaunchKernelGGL(latent_loss_kernel, dim3(rows), dim3(256), lds, s, a);
+  if (fb <= 1 && nb <= 2) LL_CASE(1, 2)
+  else if (fb <= 2 && nb <= 4) LL_CASE(2, 4)
+  else LL_CASE(3, 6)   // larger T: the kernel loops in chunks of 256 * FB bins / 256 * NB samples
+#undef LL_CASE
   hipLaunchKernelGGL(latent_loss_finish_kernel, dim3(1), dim3(256), 0, s, part, a, out6);
   return hipGetLastError();
 }

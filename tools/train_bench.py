@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--drop-path", type=float, default=0.05)
+    ap.add_argument("--latent", type=float, default=0.0, help="latent perceptual loss weight (0.3 = the v3mod2 trainer)")
+    ap.add_argument("--ln", action="store_true", help="JaT_AudioSR_V2 (LayerNorm), the model class of train_ddp_v3mod2.py")
     ap.add_argument("--split", action="store_true", help="time fwd+bwd and the optimiser separately")
     args = ap.parse_args()
     import numpy as np
@@ -33,10 +35,13 @@ def main():
 
     cfg = recipe.CONFIGS[args.config]
     C = cfg["input_channels"]
-    model = jatsr_amd.JaT_AudioSR_V3(**cfg, dropout=args.dropout, drop_path_rate=args.drop_path)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg).items()}, strict=False)
+    cls = jatsr_amd.JaT_AudioSR_V2 if args.ln else jatsr_amd.JaT_AudioSR_V3
+    model = cls(**cfg, dropout=args.dropout, drop_path_rate=args.drop_path)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg, "ln" if args.ln else "rms").items()},
+                          strict=False)
     model = model.to("cuda")
-    tr = Trainer(model, batch_size=args.B, frames=args.T, seed=1)
+    tr = Trainer(model, batch_size=args.B, frames=args.T, seed=1, latent_loss_weight=args.latent,
+                 **(dict(cfg_dropout_prob=0.0, condition_noise_ratio=0.05) if args.latent else {}))
     hr = torch.from_numpy(recipe.gaussian("train_hr", (args.B, C, args.T), 300)).cuda()
     lr = torch.from_numpy(recipe.gaussian("train_lr", (args.B, C, args.T), 301)).cuda()
     mean, std = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
