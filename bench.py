@@ -202,8 +202,8 @@ def main():
             torch.cuda.empty_cache()
             legs = {}
             mean, std = torch.zeros(C_lat, device=dev), torch.ones(C_lat, device=dev)
-            for Tt in (T, 1378):
-                trainer = Trainer(model, batch_size=B, frames=Tt, seed=1)
+            for Tt, lw in ((T, 0.0), (1378, 0.0), (1378, 0.3)):   # lw = 0.3: + the v3mod2 latent perceptual (FFT) loss
+                trainer = Trainer(model, batch_size=B, frames=Tt, seed=1, latent_loss_weight=lw)
                 hr_t = torch.from_numpy(recipe.gaussian("train_hr", (B, C_lat, Tt), 300)).to(dev)
                 lr_t = torch.from_numpy(recipe.gaussian("train_lr", (B, C_lat, Tt), 301)).to(dev)
                 for _ in range(2):
@@ -217,14 +217,15 @@ def main():
                 ts = (time.perf_counter() - ts0) / nt
                 assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"])
                 tfl = 3 * recipe.forward_flops(cfg, B, Tt) / ts / 1e12
-                legs[f"T{Tt}"] = {"ms_per_step": ts * 1e3, "latent_frames_per_s": B * Tt / ts, "tflops": tfl,
+                legs[f"T{Tt}" + ("_latent_loss" if lw else "")] = {"ms_per_step": ts * 1e3, "latent_frames_per_s": B * Tt / ts, "tflops": tfl,
                                   "mfma_frac": tfl / PEAK_BF16_TFLOPS, "loss": st["loss"], "grad_norm": st["grad_norm"],
                                   "workspace_GB": trainer.workspace_bytes() / 1e9}
                 del trainer, hr_t, lr_t
                 torch.cuda.empty_cache()
             result["train_step"] = {"workload": f"{args.config} bf16 training step B={B}/GPU (fwd + MSE + bwd + "
                                                 "clip_grad_norm 1.0 + AdamW), dropout 0.1 / DropPath 0..0.05 "
-                                                "as train_ddp_v3m2.py:82-83, one GPU", **legs}
+                                                "as train_ddp_v3m2.py:82-83; *_latent_loss: MSE + 0.3 x latent "
+                                                "perceptual loss of train_ddp_v3mod2.py (configs[3]); one GPU", **legs}
 
         # ---- CPU baseline: numpy oracle (port of the reference fp32 CPU forward) on a bounded sample --------
         if world == 1 and not args.no_cpu_baseline:
