@@ -143,6 +143,9 @@ int jat_trainer_set_latent_loss(jat_trainer* tr, double latent_weight, double fr
 /* out6 (device): {total, mse, freq, ms, consistency, weighted latent sum} of the latest jat_trainer_fwd_bwd. */
 int jat_trainer_loss_terms(jat_trainer* tr, float* out6, void* stream);
 int jat_trainer_workspace_bytes(const jat_trainer* tr, size_t* out);
+/* Re-derive every operand copy (bf16 weights and their transposes, fp32 operand tensors) from params_flat after the
+ * caller overwrote parameters — checkpoint resume, train_ddp_v3m2.py:443-500. */
+int jat_trainer_repack(jat_trainer* tr, void* stream);
 /* hr_norm, noise, z_t: [B,C,T]; cond [B,Cc,T] is modified in place: cond = (cond + cond_noise * ratio *
  * (adaptive ? clamp(std(cond), 0.5, 2) : 1)) * keep[b]   (cond_noise / keep may be NULL); t [B]. */
 int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float* cond, const float* noise,

@@ -53,6 +53,7 @@ SIGNATURES = {
                                      C.POINTER(_VP)]),
     "jat_trainer_destroy": (None, [_VP]),
     "jat_trainer_workspace_bytes": (C.c_int, [_VP, C.POINTER(_SZ)]),
+    "jat_trainer_repack": (C.c_int, [_VP, _VP]),
     "jat_trainer_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F32, _I32, _VP, _VP, _VP, _VP]),
     "jat_trainer_set_regularisers": (C.c_int, [_VP, C.POINTER(_F32), C.POINTER(_F32)]),
     "jat_trainer_set_latent_loss": (C.c_int, [_VP] + [C.c_double] * 7),

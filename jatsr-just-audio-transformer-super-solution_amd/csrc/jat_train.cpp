@@ -562,3 +562,10 @@ extern "C" int jat_k_latent_loss(const float* pred, const float* target, const f
                           (int)((double)F * strict_cutoff), (int)((double)F * soft_cutoff), loss_scale, s));
   return JAT_OK;
 }
+
+// Re-derive every operand copy (bf16 weights, transposed copies, fp32 operand tensors) from the flat master buffer,
+// e.g. after the caller overwrote parameters (checkpoint resume, train_ddp_v3m2.py:443-500).
+extern "C" int jat_trainer_repack(jat_trainer* tr, void* stream) {
+  if (!tr) return fail(JAT_E_INVALID, "null argument");
+  return repack(tr, (hipStream_t)stream);
+}

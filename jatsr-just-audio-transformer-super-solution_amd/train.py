@@ -275,6 +275,49 @@ class Trainer:
         loss, gnorm = self.optimizer_step()
         return dict(loss=loss, grad_norm=gnorm, lr=self.last_lr, step=self.global_step)
 
+    # -- validation (train_ddp_v3mod2.py:1026-1118 / train_ddp_v3m2.py:695-745) -------------------------------------------
+    @torch.no_grad()
+    def validate(self, batches, hr_mean, hr_std, lr_mean, lr_std, t=None, noise=None):
+        """Eval-mode loss over an iterable of (hr, lr) raw-latent batches: uniform t, no condition noise, no CFG dropout,
+        no Dropout / DropPath; the same loss as the training step.  Returns (avg_loss, loss_std, metrics) — the
+        reference's triple; the sums of all ranks are combined by ONE all-reduce of an 8-float vector (the reference
+        issues seven 1-float all-reduces, :1087-1096).  `t` / `noise`: optional per-batch lists (tests)."""
+        from .sampler import channel_affine
+        acc = torch.zeros(8, dtype=torch.float64, device=self.device)   # loss, steps, mse, freq, ms, cons, latent, -
+        losses = []
+        ll = self.latent_loss
+        out6 = torch.zeros(6, dtype=torch.float32, device=self.device)
+        for i, (hr, lr) in enumerate(batches):
+            hr_norm = channel_affine(hr.to(self.device, torch.float32), hr_mean, hr_std)
+            lr_norm = channel_affine(lr.to(self.device, torch.float32), lr_mean, lr_std)
+            Bv, Cv, Tv = hr_norm.shape
+            tt = t[i].to(self.device, torch.float32) if t is not None else torch.rand(Bv, device=self.device, generator=self.gen)
+            nz = noise[i].to(self.device) if noise is not None else torch.randn(hr_norm.shape, device=self.device, generator=self.gen)
+            tv = tt.view(-1, 1, 1)
+            z_t = tv * hr_norm + (1 - tv) * nz                          # plumbing-sized elementwise op, as in the reference
+            pred = self.model(z_t.contiguous(), tt.contiguous(), lr_norm)
+            rows = Bv * Cv
+            work = torch.empty((Tv * 8 + 255) // 256 * 256 + rows * 32, dtype=torch.uint8, device=self.device)
+            scratch = torch.empty_like(pred)
+            L.check(L.lib().jat_k_latent_loss(L.ptr(pred), L.ptr(hr_norm), L.ptr(lr_norm), L.ptr(scratch), L.ptr(out6), rows, Tv,
+                                              ll["latent_weight"], ll["freq_weight"], ll["ms_weight"], ll["consistency_weight"],
+                                              ll["low_freq_phase_ratio"], ll["strict_cutoff"], ll["soft_cutoff"], 1.0,
+                                              L.ptr(work), work.numel(), L.stream_ptr()))
+            o = out6.double()
+            acc[0] += o[0]; acc[1] += 1; acc[2:7] += o[1:6]
+            losses.append(float(o[0]))
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+        steps = max(float(acc[1]), 1.0)
+        avg = float(acc[0]) / steps
+        std = float(torch.tensor(losses).std()) if len(losses) > 1 else 0.0
+        metrics = {}
+        if ll["latent_weight"] != 0.0:
+            metrics = dict(zip(("mse_loss", "freq_loss", "ms_loss", "consistency_loss", "total_latent_loss"),
+                               (acc[2:7] / steps).tolist()))
+        return avg, std, metrics
+
     # -- checkpoint egress / ingest in the reference's layout (train_ddp_v3m2.py:747-770, 443-500) ----------------------
     def optimizer_state_dict(self):
         """torch.optim.AdamW.state_dict() layout, so that the reference trainer can resume from it."""
@@ -304,3 +347,22 @@ class Trainer:
                   config=dict(self.model.config(), dropout=max(self.dropout), drop_path_rate=max(self.drop_path)))
         torch.save(ck, path)
         return ck
+
+    def load_checkpoint(self, checkpoint):
+        """Resume (train_ddp_v3m2.py:443-500): model weights (prefixes stripped, strict=False), AdamW moments, step
+        counter and loss scale from a checkpoint dict or path in the reference's layout."""
+        if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        sd = checkpoint["model_state_dict"]
+        sd = {k.replace("_orig_mod.", "").replace("module.", ""): v for k, v in sd.items()}
+        own = dict(self.model.named_parameters())
+        for k, v in sd.items():
+            if k in own:
+                own[k].data.copy_(torch.as_tensor(v).to(self.device, torch.float32))   # writes through to the flat buffer
+        if checkpoint.get("optimizer_state_dict"):
+            self.load_optimizer_state_dict(checkpoint["optimizer_state_dict"])
+        if checkpoint.get("scaler_state_dict") and self.scaler.enabled:
+            self.scaler.load_state_dict(checkpoint["scaler_state_dict"])
+        self.global_step = int(checkpoint.get("global_step", self.global_step))
+        L.check(L.lib().jat_trainer_repack(self.ptr, L.stream_ptr()))   # every operand copy follows the new weights
+        return checkpoint.get("epoch", 0)

@@ -329,3 +329,44 @@ def test_v3mod2_step_vs_reference_golden(name):
     mean, std = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     st = tr.train_step(hr, lr, mean, std, mean, std)
     assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]) and tr.loss_terms()["latent"] > 0
+
+
+def test_validate_and_checkpoint_roundtrip(tmp_path):
+    """validate(): eval-mode loss with injected t / noise vs the fp64 oracles; save_checkpoint -> load_checkpoint into a
+    fresh trainer reproduces weights, moments, step counter and the next step bit for bit."""
+    from oracle import jat_oracle_train as OT
+    from oracle import latent_loss_oracle as LO
+    z, meta = load_golden("train_micro_mod2_T24")
+    kw = dict(use_grad_scaler=False, condition_noise_ratio=0.0, latent_loss_weight=0.3, seed=3)
+    m, tr = make_trainer(dict(meta, lr=1e-3, wd=0.1, clip=1.0), **kw)
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    C, B, T, salt = cfg["input_channels"], meta["B"], meta["T"], meta["salt"]
+    hr, lr, noise, t, _ = step_inputs(dict(meta, mask=[False] * B))
+    mean, std = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    avg, sd_, metrics = tr.validate([(hr, lr), (lr, hr)], mean, std, mean, std, t=[t, t], noise=[noise, noise])
+    sdw = recipe.make_state_dict(cfg, "ln", salt)
+    orc = OT.TrainOracle(cfg, sdw, "ln")
+    ref = []
+    for a, b_ in ((hr, lr), (lr, hr)):
+        an, bn, nz, tn = (x.cpu().numpy().astype(np.float64) for x in (a, b_, noise, t))
+        tv = tn.reshape(B, 1, 1)
+        pred = orc.forward(tv * an + (1 - tv) * nz, tn, bn)
+        ref.append(LO.latent_loss(pred, an, bn, latent_weight=0.3)[0])
+    assert abs(avg - np.mean([r["total"] for r in ref])) <= 3e-3 * avg
+    assert abs(metrics["mse_loss"] - np.mean([r["mse"] for r in ref])) <= 3e-3 * metrics["mse_loss"]
+    assert abs(metrics["consistency_loss"] - np.mean([r["consistency"] for r in ref])) <= 1e-2 * metrics["consistency_loss"]
+    assert sd_ == pytest.approx(float(np.std([r["total"] for r in ref], ddof=1)), rel=0.05)
+    # ---- checkpoint round trip
+    for _ in range(3):
+        tr.train_step(hr, lr, mean, std, mean, std)
+    path = str(tmp_path / "ck.pt")
+    tr.save_checkpoint(path, epoch=4)
+    m2, tr2 = make_trainer(dict(meta, lr=1e-3, wd=0.1, clip=1.0, salt=salt + 9), **kw)   # different initial weights
+    assert tr2.load_checkpoint(path) == 4
+    assert tr2.global_step == 3 and torch.equal(tr2.params, tr.params)
+    assert torch.equal(tr2.exp_avg, tr.exp_avg) and torch.equal(tr2.exp_avg_sq, tr.exp_avg_sq)
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=torch.zeros(B, dtype=torch.bool), t=t)
+    for x in (tr, tr2):
+        x.forward_backward(z_t, t2, cond, hr, cond_clean=lr, mask_seed=11)
+        x.optimizer_step(lr=1e-3)
+    assert torch.equal(tr2.grads, tr.grads) and torch.equal(tr2.params, tr.params)
