@@ -129,6 +129,12 @@ int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, int32_t n_par
                        float* grads_flat, float* exp_avg, float* exp_avg_sq, int64_t total, int32_t B, int32_t T,
                        void* stream, jat_trainer** out);
 void jat_trainer_destroy(jat_trainer* tr);
+/* Overlap of the gradient all-reduce with the backward (what DDP's bucket hooks do, train_ddp_v3m2.py:486): `hook` is
+ * called on the host thread, during enqueue, each time the last kernel writing a contiguous slice grads_flat[off, off+n)
+ * has been enqueued on the step's stream — the final layer first, then blocks depth-1 .. 0 (one slice per block,
+ * 109 MB for v3mod2), then patch_embed + t_embedder; the slices tile [0, total) exactly once per jat_trainer_fwd_bwd.
+ * The callee orders a collective behind the work enqueued so far (event on the stream) and returns.  NULL: off. */
+int jat_trainer_set_grad_hook(jat_trainer* tr, void (*hook)(int64_t off, int64_t n, void* user), void* user);
 /* Per-layer rates (host arrays [depth]): dropout[l] = the block's nn.Dropout p (jat_audiosr_v3.py:262,269,271),
  * drop_path[l] = linspace(0, drop_path_rate, depth)[l] (:372-377).  Default: all zero. */
 int jat_trainer_set_regularisers(jat_trainer* tr, const float* dropout, const float* drop_path);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "jat_trainer_workspace_bytes": (C.c_int, [_VP, C.POINTER(_SZ)]),
     "jat_trainer_repack": (C.c_int, [_VP, _VP]),
     "jat_trainer_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F32, _I32, _VP, _VP, _VP, _VP]),
+    "jat_trainer_set_grad_hook": (C.c_int, [_VP, _VP, _VP]),
     "jat_trainer_set_regularisers": (C.c_int, [_VP, C.POINTER(_F32), C.POINTER(_F32)]),
     "jat_trainer_set_latent_loss": (C.c_int, [_VP] + [C.c_double] * 7),
     "jat_trainer_loss_terms": (C.c_int, [_VP, _VP, _VP]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "jat_prof_gemm_site": (C.c_int, [_I32, _I32]),
     "jat_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),
 }
+
+GRAD_HOOK = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)   # jat_trainer_set_grad_hook callback
 
 _lib = None
 

@@ -48,6 +48,11 @@ struct jat_trainer {
   bf16_t *dy, *dh, *dxn, *dao, *dqkv, *tA, *tB, *dyf;
   int64_t o_pe_w1, o_pe_b1, o_pe_w2, o_pe_b2, o_te_w1, o_te_b1, o_te_w2, o_te_b2, o_fn, o_wf, o_bf;
   bool rms = true;
+  // gradient-ready hook (DDP overlap): called on the host, during enqueue, once the last kernel writing the slice
+  // grads_flat[off, off + n) has been enqueued — final layer first, then blocks depth-1 .. 0, then patch embed + t_embedder
+  void (*hook)(int64_t off, int64_t n, void* user) = nullptr;
+  void* hook_user = nullptr;
+  std::vector<int64_t> block_lo;       // first float of block l's parameters (depth + 1 entries: [depth] = final layer)
   std::vector<float> p_drop, p_path;   // per-layer Dropout / DropPath rates (jat_trainer_set_regularisers); default 0
   uint64_t seed = 0;                   // RNG seed of the step in flight (masks are recomputed by the backward)
   CopyJob* copy_jobs = nullptr;        // device table: fp32 master slices -> the model's fp32 operand tensors
@@ -231,6 +236,7 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
   JCHK(weight_grad(tr, tr->dyf, m->Fout, tr->xnf, D, G + tr->o_wf, G + tr->o_bf, s));
   KCHK(launch_norm_bwd(tr->x[m->depth], tr->dxn, m->final_norm, nullptr, 0, tr->dx, 0, tr->part, tr->dw_part, nullptr, nullptr, 0,
                        tr->rms ? G + tr->o_fn : nullptr, B, D, ntok, mode, s));
+  if (tr->hook) tr->hook(tr->block_lo[m->depth], tr->total - tr->block_lo[m->depth], tr->hook_user);
   for (int l = m->depth - 1; l >= 0; --l) {
     TLayer& L = tr->L[l];
     const float* mod = tr->mod + (int64_t)l * 6 * D;
@@ -257,6 +263,9 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
     KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, s));
     KCHK(launch_norm_bwd(tr->x[l], tr->dxn, m->layers[l].norm1, mod + 1 * D, mstride, tr->dx, 1, tr->part, tr->dw_part, dmod + 0 * D,
                          dmod + 1 * D, mstride, tr->rms ? G + L.o_n1 : nullptr, B, D, ntok, mode, s));
+    // adaLN modulation Linear(SiLU(t_emb)) of this block (:275-278): its six dmod slices are complete now
+    KCHK(launch_small_dw(dmod, mstride, tr->t_emb, D, G + L.o_ada_w, G + L.o_ada_b, B, 6 * D, D, 1, s));
+    if (tr->hook) tr->hook(tr->block_lo[l], tr->block_lo[l + 1] - tr->block_lo[l], tr->hook_user);
   }
   // patch embed: Linear(Kp -> bott) - GELU - Linear(bott -> D)   (jat_audiosr_v3.py:221-225); no gradient to the input
   KCHK(launch_cast_bf16(tr->dx, tr->dy, (int64_t)M * D, s));
@@ -264,16 +273,13 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
   JCHK(weight_grad(tr, tr->dy, D, tr->pe_h, m->bott, G + tr->o_pe_w2, G + tr->o_pe_b2, s));
   KCHK(launch_gelu_bwd(tr->pe_pre, tr->dh, (int64_t)M * m->bott, kNoDrop, s));
   JCHK(weight_grad(tr, tr->dh, m->bott, tr->a_patch, m->Kp, G + tr->o_pe_w1, G + tr->o_pe_b1, s));
-  // adaLN modulation Linear(SiLU(t_emb)) of every block (:275-278), then the t_embedder MLP (:364-369); fp32, B rows
-  for (int l = 0; l < m->depth; ++l) {
-    TLayer& L = tr->L[l];
-    KCHK(launch_small_dw(tr->dmod + (int64_t)l * 6 * D, mstride, tr->t_emb, D, G + L.o_ada_w, G + L.o_ada_b, B, 6 * D, D, 1, s));
-  }
+  // the t_embedder MLP (:364-369) behind all adaLN Linears; fp32, B rows
   // d silu(t_emb) = dmod [B, depth*6D] @ W_ada (the packed bf16 copy the forward multiplied with), all layers at once
   KCHK(launch_small_dx(tr->dmod, mstride, m->wada, 1, tr->small_part, tr->dt_emb, B, (int)mstride, D, 0, tr->t_emb, s));
   KCHK(launch_small_dw(tr->dt_emb, D, tr->t_h, D, G + tr->o_te_w2, G + tr->o_te_b2, B, D, D, 0, s));
   KCHK(launch_small_dx(tr->dt_emb, D, tr->P + tr->o_te_w2, 0, tr->small_part, tr->du1, B, D, D, 0, tr->u1, s));
   KCHK(launch_small_dw(tr->du1, D, tr->e_sin, D, G + tr->o_te_w1, G + tr->o_te_b1, B, D, D, 0, s));
+  if (tr->hook) tr->hook(0, tr->block_lo[0], tr->hook_user);
   return JAT_OK;
 }
 
@@ -345,6 +351,27 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     L.o_w1 = need(p + "mlp.0.weight"); L.o_b1 = need(p + "mlp.0.bias");
     L.o_w2 = need(p + "mlp.3.weight"); L.o_b2 = need(p + "mlp.3.bias");
     L.o_ada_w = need(p + "adaLN_modulation.1.weight"); L.o_ada_b = need(p + "adaLN_modulation.1.bias");
+  }
+  // contiguous parameter ranges per block for the gradient-ready hook: block l = [block_lo[l], block_lo[l+1])
+  tr->block_lo.assign(depth + 1, 0);
+  for (int l = 0; l < depth && rc == JAT_OK; ++l) {
+    const TLayer& L = tr->L[l];
+    int64_t lo = std::min(std::min(L.o_q, L.o_k), std::min(L.o_v, L.o_o));
+    lo = std::min(lo, std::min(std::min(L.o_w1, L.o_b1), std::min(L.o_w2, L.o_b2)));
+    lo = std::min(lo, std::min(L.o_ada_w, L.o_ada_b));
+    if (tr->rms) lo = std::min(lo, std::min(L.o_n1, L.o_n2));
+    tr->block_lo[l] = lo;
+  }
+  tr->block_lo[depth] = std::min(tr->o_wf, tr->o_bf);
+  if (tr->rms) tr->block_lo[depth] = std::min(tr->block_lo[depth], tr->o_fn);
+  for (int l = 0; l < depth && rc == JAT_OK; ++l)
+    if (tr->block_lo[l] >= tr->block_lo[l + 1])
+      rc = fail(JAT_E_INVALID, "parameters of block %d are not laid out before those of block %d / the final layer", l, l + 1);
+  {
+    const int64_t head_hi = std::max(std::max(tr->o_pe_w1, tr->o_pe_b1), std::max(std::max(tr->o_pe_w2, tr->o_pe_b2),
+                            std::max(std::max(tr->o_te_w1, tr->o_te_b1), std::max(tr->o_te_w2, tr->o_te_b2))));
+    if (rc == JAT_OK && head_hi >= tr->block_lo[0])
+      rc = fail(JAT_E_INVALID, "patch_embed / t_embedder parameters must precede the blocks in the flat buffer");
   }
   if (rc == JAT_OK && used != (size_t)n)
     rc = fail(JAT_E_INVALID, "%d parameters given, %zu belong to this model: every trainable tensor must be known", n, used);
@@ -455,6 +482,13 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
   if (rc != JAT_OK) { jat_trainer_destroy(tr); return rc; }
   if (hipStreamSynchronize(s) != hipSuccess) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "trainer setup failed"); }
   *out = tr;
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_set_grad_hook(jat_trainer* tr, void (*hook)(int64_t, int64_t, void*), void* user) {
+  if (!tr) return fail(JAT_E_INVALID, "null argument");
+  tr->hook = hook;
+  tr->hook_user = user;
   return JAT_OK;
 }
 

@@ -103,7 +103,7 @@ class Trainer:
                  grad_clip=1.0, cfg_dropout_prob=0.1, condition_noise_ratio=0.02, use_adaptive_noise=True,
                  warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None,
                  latent_loss_weight=0.0, freq_loss_weight=0.5, ms_loss_weight=0.5, consistency_weight=0.1,
-                 low_freq_phase_ratio=0.3, strict_cutoff=0.30, soft_cutoff=0.36):
+                 low_freq_phase_ratio=0.3, strict_cutoff=0.30, soft_cutoff=0.36, overlap_grad_allreduce=True):
         """latent_loss_weight > 0 selects the v3mod2 trainer's loss, MSE + latent perceptual loss
         (train_ddp_v3mod2.py:53-321,362-372,889-896; its TrainConfig uses 0.3 with the other defaults given here, no CFG
         dropout and condition_noise_ratio 0.05); 0 is the MSE-only loss of train_ddp_v3m2.py:585."""
@@ -158,6 +158,30 @@ class Trainer:
                                 soft_cutoff=float(soft_cutoff))
         L.check(L.lib().jat_trainer_set_latent_loss(self.ptr, *self.latent_loss.values()))
         self._terms = torch.zeros(6, dtype=torch.float32, device=dev)
+        # gradient all-reduce overlapped with the backward: one async all-reduce per parameter slice as soon as its
+        # last gradient kernel is enqueued (jat_trainer_set_grad_hook), on a side stream ordered by an event
+        self.overlap = overlap_grad_allreduce      # True: when world_size > 1; "force": also with one rank (tests)
+        self._pending, self._covered = [], 0
+        self._comm_stream = torch.cuda.Stream(device=dev)
+        self._hook = L.GRAD_HOOK(self._on_grads_ready)          # keep the ctypes thunk alive
+        L.check(L.lib().jat_trainer_set_grad_hook(self.ptr, C.cast(self._hook, C.c_void_p), None))
+
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _on_grads_ready(self, off, n, _user):
+        import torch.distributed as dist
+        if not self.overlap or not (dist.is_available() and dist.is_initialized()):
+            return
+        if self._world() == 1 and self.overlap != "force":
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ev)
+            self._pending.append(dist.all_reduce(self.grads[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._covered += n
 
     def loss_terms(self):
         """{total, mse, freq, ms, consistency, latent} of the latest step (the trainer's `latent_loss_dict`,
@@ -237,6 +261,7 @@ class Trainer:
                 raise ValueError(f"expected fp32 CUDA [{self.B}, {self.model.input_channels}, {self.T}], got "
                                  f"{tuple(x.shape)} {x.dtype} on {x.device}")
         pred = torch.empty_like(z_t) if want_pred else None
+        self._pending, self._covered = [], 0
         L.check(L.lib().jat_trainer_fwd_bwd(self.ptr, L.ptr(z_t.contiguous()), L.ptr(t.contiguous()), L.ptr(cond.contiguous()),
                                             L.ptr(target.contiguous()),
                                             L.ptr(cond_clean.contiguous()) if cond_clean is not None else None,
@@ -249,7 +274,14 @@ class Trainer:
     def optimizer_step(self, lr=None):
         """All-reduce, unscale, clip_grad_norm_(grad_clip), AdamW, re-pack.  Returns (loss, grad_norm) as floats —
         the one host synchronisation of the step, like the reference's `.item()` calls (train_ddp_v3m2.py:615,622)."""
-        world = allreduce_mean_(self.grads, self.group)
+        if self._pending:          # slices were reduced under the backward: the step's stream waits for the last of them
+            for w in self._pending:
+                w.wait()
+            assert self._covered == self.grads.numel(), "gradient hooks did not tile the flat buffer"
+            self._pending, self._covered = [], 0
+            world = self._world()
+        else:
+            world = allreduce_mean_(self.grads, self.group)
         if lr is None:
             lr = get_lr(self.global_step, self.total_steps, self.warmup_steps, self.base_lr) if self.total_steps else self.base_lr
         scale = self.scaler.scale * world

@@ -370,3 +370,46 @@ def test_validate_and_checkpoint_roundtrip(tmp_path):
         x.forward_backward(z_t, t2, cond, hr, cond_clean=lr, mask_seed=11)
         x.optimizer_step(lr=1e-3)
     assert torch.equal(tr2.grads, tr.grads) and torch.equal(tr2.params, tr.params)
+
+
+def test_gradient_allreduce_overlaps_the_backward_single_rank_rccl():
+    """DDP path on one GPU: a 1-rank RCCL group, the gradient-ready hooks fire per parameter slice (final layer, blocks
+    in reverse, patch embed + t_embedder), tile the flat buffer exactly once, and the step equals the un-hooked one bit
+    for bit (a 1-rank SUM is the identity)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    z, meta = load_golden("train_tiny_T128")
+    hr, lr, noise, t, mask = step_inputs(meta)
+    m0, tr0 = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0, overlap_grad_allreduce=False)
+    z_t, t2, cond = tr0.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    tr0.forward_backward(z_t, t2, cond, hr)
+    tr0.optimizer_step(lr=1e-4)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        m1, tr1 = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0, overlap_grad_allreduce="force")
+        calls = []
+        orig = tr1._on_grads_ready
+
+        def spy(off, n, user):
+            calls.append((off, n))
+            orig(off, n, user)
+        tr1._hook = L.GRAD_HOOK(spy)
+        L.check(L.lib().jat_trainer_set_grad_hook(tr1.ptr, __import__("ctypes").cast(tr1._hook, __import__("ctypes").c_void_p), None))
+        tr1.forward_backward(z_t, t2, cond, hr)
+        depth = recipe.CONFIGS[meta["cfg"]]["depth"]
+        assert len(calls) == depth + 2 and len(tr1._pending) == depth + 2
+        spans = sorted(calls)
+        assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        assert spans[-1][0] + spans[-1][1] == tr1.grads.numel()
+        assert calls[0][0] == max(o for o, _ in calls) and calls[-1][0] == 0       # final layer first, head last
+        tr1.optimizer_step(lr=1e-4)
+        torch.cuda.synchronize()
+        assert torch.equal(tr1.grads, tr0.grads) and torch.equal(tr1.params, tr0.params)
+    finally:
+        dist.destroy_process_group()
