@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--no-long", action="store_true", help="skip the T=4096 chunked-inference leg (configs[4])")
     ap.add_argument("--eager", action="store_true", help="replay the sampler without the hipGraph (A/B)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (configs[3])")
+    ap.add_argument("--mode", choices=["sample", "train"], default="sample",
+                    help="train: time K DDP training steps on every rank instead (configs[3]; not the headline metric)")
+    ap.add_argument("--train-T", type=int, default=1378)
+    ap.add_argument("--latent-loss", type=float, default=0.3, help="--mode train: latent perceptual loss weight (0 = MSE)")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,6 +91,45 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.mode == "train":
+        # configs[3]: DDP training step, B per GPU, gradient all-reduce over RCCL overlapped with the backward.
+        from jatsr_amd.train import Trainer
+        del sampler
+        Tt = args.train_T
+        trainer = Trainer(model, batch_size=B, frames=Tt, seed=1 + rank, latent_loss_weight=args.latent_loss)
+        hr_t = torch.from_numpy(recipe.gaussian("train_hr", (B, C_lat, Tt), 300 + rank)).to(dev)
+        lr_t = torch.from_numpy(recipe.gaussian("train_lr", (B, C_lat, Tt), 400 + rank)).to(dev)
+        mean, std = torch.zeros(C_lat, device=dev), torch.ones(C_lat, device=dev)
+        for _ in range(max(args.warmup, 1)):
+            st = trainer.train_step(hr_t, lr_t, mean, std, mean, std)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            st = trainer.train_step(hr_t, lr_t, mean, std, mean, std)
+        barrier()
+        elapsed = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"])
+        tfl = 3 * recipe.forward_flops(cfg, B, Tt) * args.steps / elapsed / 1e12
+        if rank == 0:
+            print(json.dumps({
+                "metric": "DiT training latent-frames/sec (B=28/GPU, C=1024, T=%d)" % Tt,
+                "value": world * B * Tt * args.steps / elapsed, "unit": "latent-frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"{args.config} DDP training step (MSE + {args.latent_loss} x latent perceptual loss, "
+                                       f"dropout 0.1, clip 1.0, AdamW), B={B}/GPU T={Tt}, flat-buffer gradient all-reduce "
+                                       "over RCCL overlapped with the backward", "B_per_gpu": B, "T": Tt,
+                           "parallelism": f"dp{world}"},
+                "tflops_per_gpu": tfl, "mfma_frac": tfl / PEAK_BF16_TFLOPS, "loss": st["loss"], "grad_norm": st["grad_norm"]}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     use_graph = not args.eager
     for _ in range(args.warmup):
@@ -146,7 +189,7 @@ def main():
 
         # ---- long-sequence chunked inference (BASELINE configs[4]): one file of T=4096 latent frames -> 4 chunks
         # (3 x 1378 + 478, overlap 172; infer_test_v3m2.py:340-404), equal-length chunks batched, 50-step CFG each
-        if not args.no_long:
+        if not args.no_long and world == 1:   # single-GPU diagnostics: not repeated in the N > 1 scaling runs
             T_long = 4096
             lr_long = torch.from_numpy(recipe.gaussian("lr_long", (C_lat, T_long), 9)).to(dev)
             mean = torch.zeros(C_lat, device=dev)
@@ -196,14 +239,14 @@ def main():
         # ---- training step (BASELINE configs[3]; train_ddp_v3m2.py:533-622): forward + MSE + backward + clip + AdamW on
         # hr, lr [B,1024,T] with U-shaped t, cond noise and CFG dropout; T=512 for comparability with the headline and
         # T=1378 (the reference's target_frames).  Runs last: it updates the weights.  FLOPs = 3 x forward closed form.
-        if not args.no_train:
+        if not args.no_train and world == 1:
             from jatsr_amd.train import Trainer
             del sampler
             torch.cuda.empty_cache()
             legs = {}
             mean, std = torch.zeros(C_lat, device=dev), torch.ones(C_lat, device=dev)
             for Tt, lw in ((T, 0.0), (1378, 0.0), (1378, 0.3)):   # lw = 0.3: + the v3mod2 latent perceptual (FFT) loss
-                trainer = Trainer(model, batch_size=B, frames=Tt, seed=1, latent_loss_weight=lw)
+                trainer = Trainer(model, batch_size=B, frames=Tt, seed=1, latent_loss_weight=lw, distributed=False)   # rank-0-only leg
                 hr_t = torch.from_numpy(recipe.gaussian("train_hr", (B, C_lat, Tt), 300)).to(dev)
                 lr_t = torch.from_numpy(recipe.gaussian("train_lr", (B, C_lat, Tt), 301)).to(dev)
                 for _ in range(2):

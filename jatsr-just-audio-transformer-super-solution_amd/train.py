@@ -103,10 +103,12 @@ class Trainer:
                  grad_clip=1.0, cfg_dropout_prob=0.1, condition_noise_ratio=0.02, use_adaptive_noise=True,
                  warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None,
                  latent_loss_weight=0.0, freq_loss_weight=0.5, ms_loss_weight=0.5, consistency_weight=0.1,
-                 low_freq_phase_ratio=0.3, strict_cutoff=0.30, soft_cutoff=0.36, overlap_grad_allreduce=True):
+                 low_freq_phase_ratio=0.3, strict_cutoff=0.30, soft_cutoff=0.36, overlap_grad_allreduce=True,
+                 distributed=True):
         """latent_loss_weight > 0 selects the v3mod2 trainer's loss, MSE + latent perceptual loss
         (train_ddp_v3mod2.py:53-321,362-372,889-896; its TrainConfig uses 0.3 with the other defaults given here, no CFG
-        dropout and condition_noise_ratio 0.05); 0 is the MSE-only loss of train_ddp_v3m2.py:585."""
+        dropout and condition_noise_ratio 0.05); 0 is the MSE-only loss of train_ddp_v3m2.py:585.
+        distributed=False: never issue a collective even if a process group exists (a single rank timing a local step)."""
         L.require_gpu()
         self.model = model
         self.B, self.T = int(batch_size), int(frames)
@@ -117,6 +119,7 @@ class Trainer:
         self.warmup_steps, self.total_steps = warmup_steps, total_steps
         self.scaler = GradScaler(enabled=use_grad_scaler)
         self.group = process_group
+        self.distributed = bool(distributed)
         self.global_step = 0
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -166,13 +169,17 @@ class Trainer:
         self._hook = L.GRAD_HOOK(self._on_grads_ready)          # keep the ctypes thunk alive
         L.check(L.lib().jat_trainer_set_grad_hook(self.ptr, C.cast(self._hook, C.c_void_p), None))
 
+    def _dist_on(self):
+        import torch.distributed as dist
+        return self.distributed and dist.is_available() and dist.is_initialized()
+
     def _world(self):
         import torch.distributed as dist
-        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        return dist.get_world_size(self.group) if self._dist_on() else 1
 
     def _on_grads_ready(self, off, n, _user):
         import torch.distributed as dist
-        if not self.overlap or not (dist.is_available() and dist.is_initialized()):
+        if not self.overlap or not self._dist_on():
             return
         if self._world() == 1 and self.overlap != "force":
             return
@@ -203,7 +210,7 @@ class Trainer:
     def step_seed(self, step=None):
         """64-bit mask seed of a step: splitmix64 of (trainer seed, step index, rank)."""
         import torch.distributed as dist
-        rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        rank = dist.get_rank(self.group) if self._dist_on() else 0
         x = (self.mask_seed + 0x9E3779B97F4A7C15 * ((self.global_step if step is None else step) * 4096 + rank + 1)) & (2 ** 64 - 1)
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
@@ -281,7 +288,7 @@ class Trainer:
             self._pending, self._covered = [], 0
             world = self._world()
         else:
-            world = allreduce_mean_(self.grads, self.group)
+            world = allreduce_mean_(self.grads, self.group) if self._dist_on() else 1
         if lr is None:
             lr = get_lr(self.global_step, self.total_steps, self.warmup_steps, self.base_lr) if self.total_steps else self.base_lr
         scale = self.scaler.scale * world
@@ -339,7 +346,7 @@ class Trainer:
             acc[0] += o[0]; acc[1] += 1; acc[2:7] += o[1:6]
             losses.append(float(o[0]))
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self._dist_on() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
         steps = max(float(acc[1]), 1.0)
         avg = float(acc[0]) / steps

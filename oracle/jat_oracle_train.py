@@ -63,7 +63,8 @@ def drop_mult(seed, site, p, shape):
     thresh = 4294967295 if t >= 4294967295.0 else int(t)
     idx = np.arange(int(np.prod(shape)), dtype=np.uint64)
     lo, hi = idx & _M32, idx >> np.uint64(32)
-    r = _hash32(_hash32(lo ^ k0) ^ ((hi * np.uint64(0x9e3779b9) + k1) & _M32))
+    rot = ((hi << np.uint64(13)) | (hi >> np.uint64(19))) & _M32
+    r = _hash32(lo ^ k0 ^ rot) ^ k1
     inv_keep = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
     return np.where(r < np.uint64(thresh), 0.0, inv_keep).reshape(shape)
 
