@@ -179,6 +179,10 @@ CONFIGS = {
                    num_q_heads=20, num_kv_heads=4, bottleneck_dim=512, mlp_ratio=4.0),
     "tiny": dict(input_channels=1024, cond_channels=1024, patch_len=4, hidden_size=512, depth=12,
                  num_q_heads=8, num_kv_heads=4, bottleneck_dim=512, mlp_ratio=4.0),
+    # v3mod2's layer dimensions (D=1280, 20Q/4KV, MLP 5120, 1024 channels) at depth 2: full-width parity cases that a
+    # CPU oracle can afford
+    "wide2": dict(input_channels=1024, cond_channels=1024, patch_len=4, hidden_size=1280, depth=2,
+                  num_q_heads=20, num_kv_heads=4, bottleneck_dim=512, mlp_ratio=4.0),
     "micro": dict(input_channels=32, cond_channels=32, patch_len=4, hidden_size=256, depth=2,
                   num_q_heads=4, num_kv_heads=2, bottleneck_dim=128, mlp_ratio=4.0),
 }

@@ -173,7 +173,8 @@ def test_cond_noise_and_training_loop_reduce_loss():
 
 
 @pytest.mark.parametrize("cfg_name,B,T,norm,salt", [("micro", 5, 70, "rms", 11), ("micro", 1, 9, "ln", 12),
-                                                     ("tiny", 3, 260, "rms", 13)])
+                                                     ("tiny", 3, 260, "rms", 13), ("wide2", 2, 130, "rms", 21),
+                                                     ("wide2", 1, 300, "ln", 22)])
 def test_train_step_vs_numpy_oracle(cfg_name, B, T, norm, salt):
     """Shapes and seeds outside the fixtures (odd batch, T % 4 != 0, N not a multiple of 16 / 64): HIP gradients vs the
     numpy oracle's hand-derived fp64 backward (itself pinned to the reference in tests/test_train_cpu.py)."""
@@ -413,3 +414,28 @@ def test_gradient_allreduce_overlaps_the_backward_single_rank_rccl():
         assert torch.equal(tr1.grads, tr0.grads) and torch.equal(tr1.params, tr0.params)
     finally:
         dist.destroy_process_group()
+
+
+def test_dropout_full_width_vs_numpy_oracle():
+    """Dropout 0.1 / DropPath at v3mod2's layer width (GQA groups of 5, D = 1280, MLP 5120): kernels regenerate the masks
+    the numpy mirror builds from the same seed."""
+    from oracle import jat_oracle_train as OT
+    cfg_name, B, T, salt, seed = "wide2", 2, 132, 31, 0xC0FFEE1234
+    cfg = recipe.CONFIGS[cfg_name]
+    C = cfg["input_channels"]
+    meta = dict(cfg=cfg_name, norm="rms", salt=salt, B=B, T=T, lr=1e-4, wd=0.1, clip=1.0)
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    rates, paths = [0.1, 0.1], [0.0, 0.5]
+    tr.set_regularisers(rates, paths)
+    z_t = recipe.gaussian("zt", (B, C, T), salt)
+    cond = recipe.gaussian("cond", (B, C, T), salt + 1)
+    target = recipe.gaussian("target", (B, C, T), salt + 2)
+    t = np.asarray([0.2, 0.8], np.float32)
+    tr.forward_backward(cuda(z_t), cuda(t), cuda(cond), cuda(target), mask_seed=seed)
+    sd = recipe.make_state_dict(cfg, "rms", salt)
+    loss, grads, _ = OT.TrainOracle(cfg, sd, "rms").loss_and_grads(z_t, t, cond, target, plan=OT.DropPlan(seed, rates, paths))
+    assert abs(float(tr._scal[0]) - loss) <= LOSS_TOL * loss
+    gn = math.sqrt(sum(float((g * g).sum()) for g in grads.values()))
+    for k, g in grads.items():
+        r = rel_l2(tr.grad(k).cpu().numpy(), g)
+        assert r <= (GRAD_TOL if np.linalg.norm(g) >= 1e-3 * gn else GRAD_TOL_SMALL), f"{k}: {r:.3e}"
