@@ -303,7 +303,9 @@ static int pick_variant(int M, int N, int nbatch = 1) {
     const long t = (long)((M + c.bm - 1) / c.bm) * (N / c.bn) * nbatch;
     const long rounds = (t + c.slots - 1) / c.slots;
     double score = c.f * (double)t / (double)(rounds * c.slots);
-    if (c.slots == 256 && rounds > 1) score *= 0.85;
+    // multi-round penalty: the 12-wave DMA-wave variants (25, 26) pay their un-overlapped prologue/epilogue per round;
+    // the 8-wave 256x256 tile (21) does not (M = 9660, N = 5120: 110 us vs 124 us for 128x160, tools/gemm_shapes_bench.py)
+    if (c.slots == 256 && rounds > 1 && c.id != 21) score *= 0.85;
     if (score > best_score) { best_score = score; best = c.id; }
   }
   return best;
