@@ -5,6 +5,7 @@
 // All reductions are fixed-order (partials + a finishing kernel): no atomics, a step is bit-reproducible.
 #include "jat_kernels.h"
 #include "jat_rng.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -1206,6 +1207,181 @@ __global__ void __launch_bounds__(256) latent_loss_kernel(const LatentLossArgs a
   __syncthreads();
   if (tid < 8) a.part[row * 8 + tid] = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
 }
+// ---- the same loss with the DFTs factored T = N1 * N2 (Cooley-Tukey, two stages, any factor pair) -------------------------
+// forward, n = N2 n1 + n2:   Y[k1][n2] = sum_n1 x[N2 n1 + n2] W^(k1 N2 n1)      (k1 <= N1/2; Y[N1-k1] = conj Y[k1], x real)
+//                            X[k]      = sum_n2 Y[k mod N1][n2] W^(k n2)          (k < F)           W = e^{-2 pi i / T}
+// adjoint:                   Z[k1][n2] = sum_{k = k1 (mod N1), k < F} g_k W^(-k n2)
+//                            s[N2 n1 + n2] = Re sum_k1 Z[k1][n2] W^(-k1 N2 n1)
+// T (N1 + N2) complex MACs per transform instead of T^2 / 2: 10 x fewer at T = 1378 = 26 * 53.  All twiddles come from the
+// one exact table W^m (m < T) with incrementally reduced indices.
+struct SpecNorm { float n_log, n_low, n_str, n_tr; int bw; bool use_lr; };
+__device__ __forceinline__ float2 spectral_terms(const LatentLossArgs& a, const SpecNorm& nm, int k, float pa, float pb, float ha,
+                                                 float hb, float ra, float rb, float* acc) {
+  float ga = 0.f, gb = 0.f;
+  const float pm = sqrtf(pa * pa + pb * pb), hm = sqrtf(ha * ha + hb * hb);
+  {
+    const float d = __logf(pm + 1e-7f) - __logf(hm + 1e-7f);
+    acc[1] += fabsf(d);
+    if (pm > 0.f && d != 0.f) {
+      const float c = a.fw * (d > 0.f ? 1.f : -1.f) / (pm + 1e-7f) * nm.n_log / pm;
+      ga += c * pa; gb += c * pb;
+    }
+  }
+  if (k < a.low) {
+    const float da = pa - ha, db = pb - hb, m = sqrtf(da * da + db * db);
+    acc[2] += m;
+    if (m > 0.f) { const float c = a.fw * 0.1f * nm.n_low / m; ga += c * da; gb += c * db; }
+  }
+  if (nm.use_lr) {
+    if (k < a.strict) {
+      const float da = pa - ra, db = pb - rb, m = sqrtf(da * da + db * db);
+      acc[6] += m;
+      if (m > 0.f) { const float c = a.cw * nm.n_str / m; ga += c * da; gb += c * db; }
+    } else if (k < a.soft) {
+      const float wk = nm.bw > 1 ? 1.0f - (float)(k - a.strict) / (float)(nm.bw - 1) : 1.0f;
+      const float rm = sqrtf(ra * ra + rb * rb), d = pm - rm;
+      acc[7] += wk * fabsf(d);
+      if (pm > 0.f && d != 0.f) { const float c = a.cw * wk * (d > 0.f ? 1.f : -1.f) * nm.n_tr / pm; ga += c * pa; gb += c * pb; }
+    }
+  }
+  return float2{ga, gb};
+}
+// time-domain terms of sample n (MSE, multi-scale L1) and the output gradient
+__device__ __forceinline__ void time_terms(const LatentLossArgs& a, const float* sp, const float* sh, int n, float s, int64_t row,
+                                           float* acc) {
+  const int T = a.T, T2 = T / 2, T4 = T / 4;
+  const float rows_f = (float)a.rows;
+  const float e = sp[n] - sh[n];
+  acc[0] += e * e;
+  acc[3] += fabsf(e);
+  float gt = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * a.inv_n;
+  if (n < 2 * T2) {
+    const int j = n >> 1;
+    const float q = 0.5f * ((sp[2 * j] - sh[2 * j]) + (sp[2 * j + 1] - sh[2 * j + 1]));
+    if ((n & 1) == 0) acc[4] += fabsf(q);
+    gt += (q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f)) * 0.5f / (rows_f * T2);
+  }
+  if (n < 4 * T4) {
+    const int j = n >> 2;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q += sp[4 * j + u] - sh[4 * j + u];
+    q *= 0.25f;
+    if ((n & 3) == 0) acc[5] += fabsf(q);
+    gt += (q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f)) * 0.25f / (rows_f * T4);
+  }
+  a.dpred[row * T + n] = a.gscale * 2.0f * e * a.inv_n + a.lw * a.gscale * (s + a.mw * gt * (1.0f / 3.0f));
+}
+__global__ void __launch_bounds__(256) latent_loss_fft_kernel(const LatentLossArgs a, int N1, int N2) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = a.T, F = a.F, tid = threadIdx.x, N1h = N1 / 2 + 1;
+  float* sp = sm;
+  float* sh = sp + T;
+  float* sr = sh + T;
+  float2* stw = (float2*)(sr + T);
+  float2* sg = stw + T;                 // [F]
+  float2* sY = sg + F;                  // [3][N1h][N2]; later Z [N1][N2]
+  float* red = (float*)(sY + max(3 * N1h * N2, T));
+  const int64_t row = blockIdx.x;
+  SpecNorm nm;
+  nm.use_lr = a.lr != nullptr && a.cw != 0.f;
+  for (int n = tid; n < T; n += 256) {
+    sp[n] = a.pred[row * T + n];
+    sh[n] = a.target[row * T + n];
+    sr[n] = nm.use_lr ? a.lr[row * T + n] : 0.f;
+    stw[n] = a.tw[n];
+  }
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const float rows_f = (float)a.rows;
+  nm.n_log = 1.0f / (rows_f * F);
+  nm.n_low = a.low > 0 ? 1.0f / (rows_f * a.low) : 0.f;
+  nm.n_str = a.strict > 0 ? 1.0f / (rows_f * a.strict) : 0.f;
+  nm.bw = a.soft - a.strict;
+  nm.n_tr = nm.bw > 0 ? 1.0f / (rows_f * nm.bw) : 0.f;
+  __syncthreads();
+  // stage 1: N1-point DFTs over the strided samples, three signals at once
+  const int plane = N1h * N2;
+  for (int o = tid; o < plane; o += 256) {
+    const int k1 = o / N2, n2 = o - k1 * N2;
+    const int step = (k1 * N2) % T;
+    float pa = 0.f, pb = 0.f, ha = 0.f, hb = 0.f, ra = 0.f, rb = 0.f;
+    int idx = 0;
+    for (int n1 = 0; n1 < N1; ++n1) {
+      const float2 w = stw[idx];
+      const int n = N2 * n1 + n2;
+      const float x = sp[n], y = sh[n], z = sr[n];
+      pa += x * w.x; pb -= x * w.y;
+      ha += y * w.x; hb -= y * w.y;
+      ra += z * w.x; rb -= z * w.y;
+      idx += step; if (idx >= T) idx -= T;
+    }
+    sY[o] = float2{pa, pb};
+    sY[plane + o] = float2{ha, hb};
+    sY[2 * plane + o] = float2{ra, rb};
+  }
+  __syncthreads();
+  // stage 2: X[k] = sum_n2 Y[k mod N1][n2] W^(k n2), loss terms, spectral gradient
+  for (int k = tid; k < F; k += 256) {
+    int k1 = k % N1;
+    const bool cj = k1 > N1 / 2;      // Y[k1] = conj(Y[N1 - k1])
+    if (cj) k1 = N1 - k1;
+    const float sgn = cj ? -1.f : 1.f;
+    const float2* yp = sY + k1 * N2;
+    float pa = 0.f, pb = 0.f, ha = 0.f, hb = 0.f, ra = 0.f, rb = 0.f;
+    int idx = 0;
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const float2 w = stw[idx];       // W^m = (cos, -sin): (yr + i yi)(c - i s) = (yr c + yi s) + i (yi c - yr s)
+      float2 y = yp[n2];
+      y.y *= sgn;
+      pa += y.x * w.x + y.y * w.y; pb += y.y * w.x - y.x * w.y;
+      y = yp[plane + n2]; y.y *= sgn;
+      ha += y.x * w.x + y.y * w.y; hb += y.y * w.x - y.x * w.y;
+      y = yp[2 * plane + n2]; y.y *= sgn;
+      ra += y.x * w.x + y.y * w.y; rb += y.y * w.x - y.x * w.y;
+      idx += k; if (idx >= T) idx -= T;
+    }
+    sg[k] = spectral_terms(a, nm, k, pa, pb, ha, hb, ra, rb, acc);
+  }
+  __syncthreads();
+  // stage 3: Z[k1][n2] = sum_{k = k1 (mod N1), k < F} g_k W^(-k n2)      (overwrites Y)
+  float2* sZ = sY;
+  for (int o = tid; o < T; o += 256) {
+    const int k1 = o / N2, n2 = o - k1 * N2;
+    int idx = (k1 * n2) % T;
+    const int step = (int)(((long long)N1 * n2) % T);
+    float zr = 0.f, zi = 0.f;
+    for (int k = k1; k < F; k += N1) {
+      const float2 w = stw[idx], g = sg[k];   // W^-m = (cos, +sin)
+      zr += g.x * w.x - g.y * w.y;
+      zi += g.x * w.y + g.y * w.x;
+      idx += step; if (idx >= T) idx -= T;
+    }
+    sZ[o] = float2{zr, zi};
+  }
+  __syncthreads();
+  // stage 4: s[N2 n1 + n2] = Re sum_k1 Z[k1][n2] W^(-k1 N2 n1), then the time-domain terms and the output
+  for (int n = tid; n < T; n += 256) {
+    const int n1 = n / N2, n2 = n - n1 * N2;
+    const int step = (N2 * n1) % T;
+    float sv = 0.f;
+    int idx = 0;
+    for (int k1 = 0; k1 < N1; ++k1) {
+      const float2 w = stw[idx], z = sZ[k1 * N2 + n2];
+      sv += z.x * w.x - z.y * w.y;
+      idx += step; if (idx >= T) idx -= T;
+    }
+    time_terms(a, sp, sh, n, sv, row, acc);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = wave_sum_t(acc[i]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[(tid >> 6) * 8 + i] = acc[i];
+  __syncthreads();
+  if (tid < 8) a.part[row * 8 + tid] = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
+}
 // out[0] = total, [1] = mse, [2] = freq, [3] = ms, [4] = cons, [5] = fw*freq + mw*ms + cw*cons
 __global__ void __launch_bounds__(256) latent_loss_finish_kernel(const float* __restrict__ part, const LatentLossArgs a,
                                                                  float* __restrict__ out) {
@@ -1248,6 +1424,26 @@ hipError_t launch_latent_loss(const float* pred, const float* target, const floa
   a.inv_n = 1.0f / ((float)rows * (float)T);
   const size_t lds = (size_t)(3 * T) * 4 + (size_t)(T + a.F) * 8 + 32 * 4;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  int N1 = 1;                       // largest divisor of T not above sqrt(T)
+  for (int d = 2; d * d <= T; ++d)
+    if (T % d == 0) N1 = d;
+  static const int direct_env = getenv("JAT_LOSS_DIRECT_DFT") ? atoi(getenv("JAT_LOSS_DIRECT_DFT")) : 0;   // A/B
+  if (N1 >= 2 && !direct_env) {
+    const int N2 = T / N1, N1h = N1 / 2 + 1;
+    const int ybuf = 3 * N1h * N2 > T ? 3 * N1h * N2 : T;
+    const size_t lds2 = (size_t)(3 * T) * 4 + (size_t)(T + a.F + ybuf) * 8 + 32 * 4;
+    if (lds2 <= 160 * 1024) {
+      static size_t attr2 = 0;
+      if (lds2 > attr2) {
+        hipError_t e = hipFuncSetAttribute((const void*)latent_loss_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        attr2 = lds2;
+      }
+      hipLaunchKernelGGL(latent_loss_fft_kernel, dim3(rows), dim3(256), lds2, s, a, N1, N2);
+      hipLaunchKernelGGL(latent_loss_finish_kernel, dim3(1), dim3(256), 0, s, part, a, out6);
+      return hipGetLastError();
+    }
+  }
   const int fb = (a.F + 255) / 256, nb = (T + 255) / 256;
 #define LL_CASE(FBv, NBv)                                                                                              \
   {                                                                                                                    \

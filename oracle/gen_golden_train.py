@@ -295,6 +295,7 @@ def main(which):
         loss_case("T24", 2, 32, 24)
         loss_case("T22", 3, 32, 22, salt=1)
         loss_case("T9", 1, 32, 9, salt=2)                 # odd T, empty / one-bin bands
+        loss_case("T23", 2, 32, 23, salt=4)               # prime T: no factorisation, the direct-DFT kernel
         loss_case("T1378", 1, 64, 1378, salt=3)           # the trainer's crop: 690 bins, bands at 207 / 248
         mod2_step_case("micro_mod2_T24", "micro", 2, 24, [0.1, 0.85], salt=2)
         mod2_step_case("tiny_mod2_T128", "tiny", 2, 128, [0.2, 0.9], salt=1, strides=(61, 53))

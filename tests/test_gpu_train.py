@@ -253,7 +253,7 @@ def test_droppath_outcomes_per_sample():
     assert len(joint) > 4                       # the samples of a batch are masked independently
 
 
-@pytest.mark.parametrize("name", ["train_loss_T24", "train_loss_T22", "train_loss_T9", "train_loss_T1378"])
+@pytest.mark.parametrize("name", ["train_loss_T24", "train_loss_T22", "train_loss_T9", "train_loss_T23", "train_loss_T1378"])
 def test_latent_loss_kernel_vs_reference_classes(name):
     """MSE + latent perceptual loss kernel (direct fp32 DFT + adjoint) vs the reference's loss classes under autograd
     (fp32 torch.fft): every term within 2e-5 relative, the gradient w.r.t. the prediction within rel-L2 2e-4."""

@@ -176,7 +176,7 @@ def _loss_inputs(meta):
     return pred, target, lr
 
 
-@pytest.mark.parametrize("name", ["train_loss_T24", "train_loss_T22", "train_loss_T9", "train_loss_T1378"])
+@pytest.mark.parametrize("name", ["train_loss_T24", "train_loss_T22", "train_loss_T9", "train_loss_T23", "train_loss_T1378"])
 def test_latent_loss_oracle_matches_reference_classes(name):
     """MSE + latent perceptual loss of the v3mod2 trainer: the fixture ran the reference's own loss classes (taken from
     train_ddp_v3mod2.py with `ast`) under autograd in fp32; the numpy oracle (fp64) must agree to fp32-FFT accuracy."""
