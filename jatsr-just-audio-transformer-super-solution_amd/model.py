@@ -59,6 +59,7 @@ class _Handle:
         self.norm_mode = norm_mode
         self.ptr = C.c_void_p()
         self.version = None
+        self.epoch = 0          # bumped when a trainer updates the weights in place (invalidates cached samplers)
         self.device = None
         self._ws = None
         c = L.JatConfig(cfg["input_channels"], cfg["cond_channels"], cfg["patch_len"], cfg["hidden_size"],

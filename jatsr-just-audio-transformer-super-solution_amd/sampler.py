@@ -23,7 +23,7 @@ class Sampler:
         self.B, self.T, self.steps, self.cfg_scale = int(B), int(T), int(num_steps), float(cfg_scale)
         h = model._get_handle()
         self._handle = h
-        self._version = h.version
+        self._version = (h.version, getattr(h, "epoch", 0))   # epoch: bumped by jatsr_amd.train after every weight update
         self.ptr = C.c_void_p()
         L.check(L.lib().jat_sampler_create(h.ptr, self.B, self.T, self.steps, self.cfg_scale, C.byref(self.ptr)))
 
@@ -51,7 +51,7 @@ def _cached_sampler(model, B, T, num_steps, cfg_scale):
     key = (B, T, num_steps, float(cfg_scale))
     s = cache.get(key)
     h = model._get_handle()  # repacks if the weights changed
-    if s is None or s._version != h.version:
+    if s is None or s._version != (h.version, getattr(h, "epoch", 0)):
         s = Sampler(model, B, T, num_steps, cfg_scale)
         cache[key] = s
     return s

@@ -301,6 +301,7 @@ class Trainer:
         self.scaler.update(found_inf)
         if not found_inf:
             self.global_step += 1
+            self._handle.epoch += 1      # the weights changed under the model: cached samplers (mod tables, graphs) are stale
         self.last_lr = lr
         return loss, gnorm
 
@@ -404,4 +405,5 @@ class Trainer:
             self.scaler.load_state_dict(checkpoint["scaler_state_dict"])
         self.global_step = int(checkpoint.get("global_step", self.global_step))
         L.check(L.lib().jat_trainer_repack(self.ptr, L.stream_ptr()))   # every operand copy follows the new weights
+        self._handle.epoch += 1
         return checkpoint.get("epoch", 0)

@@ -439,3 +439,25 @@ def test_dropout_full_width_vs_numpy_oracle():
     for k, g in grads.items():
         r = rel_l2(tr.grad(k).cpu().numpy(), g)
         assert r <= (GRAD_TOL if np.linalg.norm(g) >= 1e-3 * gn else GRAD_TOL_SMALL), f"{k}: {r:.3e}"
+
+
+def test_sampler_follows_trained_weights():
+    """The cached hipGraph sampler (modulation tables, packed weights) is rebuilt after an optimiser step."""
+    import jatsr_amd
+    z, meta = load_golden("train_micro_T24")
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    z0 = noise.clone()
+    a = jatsr_amd.flow_matching_sample(m, lr, num_steps=4, cfg_scale=3.0, verbose=False, z0=z0)
+    a2 = jatsr_amd.flow_matching_sample(m, lr, num_steps=4, cfg_scale=3.0, verbose=False, z0=z0)
+    assert torch.equal(a, a2)
+    tr.base_lr = 1e-2
+    tr.train_step(hr, lr, torch.zeros(32, device="cuda"), torch.ones(32, device="cuda"), torch.zeros(32, device="cuda"),
+                  torch.ones(32, device="cuda"))
+    b = jatsr_amd.flow_matching_sample(m, lr, num_steps=4, cfg_scale=3.0, verbose=False, z0=z0)
+    assert not torch.equal(a, b)
+    # and it equals a sampler built from scratch on a copy of the updated weights
+    m2 = type(m)(**recipe.CONFIGS[meta["cfg"]], dropout=0.0, drop_path_rate=0.0)
+    m2.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, strict=False)
+    c = jatsr_amd.flow_matching_sample(m2.to("cuda").eval(), lr, num_steps=4, cfg_scale=3.0, verbose=False, z0=z0)
+    assert torch.equal(b, c)
