@@ -796,11 +796,17 @@ hipError_t launch_adamw(float* p, float* g, float* m, float* v, int64_t n, const
 // dW[n][k] = sum_b dy[b][n] * x[b][k]   (optionally x -> silu(x));   db[n] = sum_b dy[b][n]
 // One block = DW_R output rows; a thread owns 4 consecutive k (float4 stores) and keeps DW_R x 4 accumulators.
 constexpr int DW_R = 16;
-__global__ void __launch_bounds__(256) small_dw_kernel(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ x,
+__global__ void __launch_bounds__(320) small_dw_kernel(const float* __restrict__ dy, int64_t ldy, const float* __restrict__ x,
                                                        int64_t ldx, float* __restrict__ dW, float* __restrict__ db, int B,
                                                        int N, int K, int silu_x) {
+  __shared__ __attribute__((aligned(16))) float sdy[64][DW_R];   // this block's dy rows, b-major: broadcast reads in the loop
   const int n0 = blockIdx.x * DW_R;
-  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+  for (int i = threadIdx.x; i < B * DW_R; i += blockDim.x) {
+    const int b = i / DW_R, r = i - b * DW_R;
+    sdy[b][r] = (n0 + r < N) ? dy[(int64_t)b * ldy + n0 + r] : 0.f;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
     f32x4_t acc[DW_R];
 #pragma unroll
     for (int r = 0; r < DW_R; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -811,10 +817,12 @@ __global__ void __launch_bounds__(256) small_dw_kernel(const float* __restrict__
         for (int j = 0; j < 4; ++j) xv[j] = xv[j] / (1.0f + __expf(-xv[j]));
       }
 #pragma unroll
-      for (int r = 0; r < DW_R; ++r) {
-        const float d = (n0 + r < N) ? dy[(int64_t)b * ldy + n0 + r] : 0.f;   // uniform across the block
+      for (int q = 0; q < DW_R / 4; ++q) {
+        const f32x4_t d = *(const f32x4_t*)&sdy[b][q * 4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[r][j] += d * xv[j];
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[q * 4 + e][j] += d[e] * xv[j];
       }
     }
 #pragma unroll
@@ -823,7 +831,7 @@ __global__ void __launch_bounds__(256) small_dw_kernel(const float* __restrict__
   }
   if (db && threadIdx.x < DW_R && n0 + threadIdx.x < N) {
     float bsum = 0.f;
-    for (int b = 0; b < B; ++b) bsum += dy[(int64_t)b * ldy + n0 + threadIdx.x];
+    for (int b = 0; b < B; ++b) bsum += sdy[b][threadIdx.x];
     db[n0 + threadIdx.x] = bsum;
   }
 }
@@ -883,8 +891,9 @@ __global__ void __launch_bounds__(256) small_dx_finish_kernel(const float* __res
 }
 hipError_t launch_small_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dW, float* db, int B, int N,
                            int K, int silu_x, hipStream_t s) {
-  if (K % 4 != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(small_dw_kernel, dim3((N + DW_R - 1) / DW_R), dim3(256), 0, s, dy, ldy, x, ldx, dW, db, B, N, K, silu_x);
+  if (K % 4 != 0 || B > 64) return hipErrorInvalidValue;
+  const int threads = K / 4 >= 320 ? 320 : 64 * ((K / 4 + 63) / 64);   // one pass over K for K = 1280
+  hipLaunchKernelGGL(small_dw_kernel, dim3((N + DW_R - 1) / DW_R), dim3(threads), 0, s, dy, ldy, x, ldx, dW, db, B, N, K, silu_x);
   return hipGetLastError();
 }
 int small_dx_slab(int N) { return N >= 16384 ? 256 : 32; }
