@@ -44,7 +44,7 @@ struct jat_trainer {
   bf16_t *a_patch, *pe_pre, *pe_h, *xnf, *t_silu, *pe_w2T, *wfinalT;
   float *e_sin, *u1, *t_h, *t_emb, *mod, *pred;
   // backward scratch
-  float *dx, *dpred, *dmod, *part, *red_part, *scal, *delta, *dwqkv, *dsilu, *dt_emb, *du1, *small_part;
+  float *dx, *dpred, *dmod, *part, *red_part, *scal, *delta, *dwqkv, *dt_emb, *du1, *small_part;
   bf16_t *dy, *dh, *dxn, *dao, *dqkv, *tA, *tB, *dyf;
   int64_t o_pe_w1, o_pe_b1, o_pe_w2, o_pe_b2, o_te_w1, o_te_b1, o_te_w2, o_te_b2, o_fn, o_wf, o_bf;
   bool rms = true;
@@ -416,7 +416,7 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     tr->ll_part = (float*)take((size_t)B * m->Cin * 8 * 4);
     tr->delta = (float*)take((size_t)B * m->Hq * ntok * 4);
     tr->dwqkv = (float*)take((size_t)Nqkv * D * 4);
-    tr->dsilu = (float*)take((size_t)B * D * 4); tr->dt_emb = (float*)take((size_t)B * D * 4);
+    tr->dt_emb = (float*)take((size_t)B * D * 4);
     tr->du1 = (float*)take((size_t)B * D * 4);
     {
       const int Nall = depth * 6 * D;
