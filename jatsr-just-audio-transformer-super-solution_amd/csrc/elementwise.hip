@@ -452,3 +452,33 @@ hipError_t launch_crossfade_pair(const float* prev, int Tp, const float* cur, in
                      overlap, out, rows);
   return hipGetLastError();
 }
+
+// ---- finish of a split-K gated-residual GEMM (small-M inference): fixed summation order, one pass over x -------------
+__global__ void __launch_bounds__(256) splitk_resid_finish_kernel(const float* __restrict__ part, int nsplit, int64_t stride,
+                                                                  const float* __restrict__ bias, const float* __restrict__ gate,
+                                                                  int64_t gate_bstride, int ntok, float* __restrict__ x, int M,
+                                                                  int N) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread = 4 columns
+  const int per_row = N / 4;
+  if (i >= (int64_t)M * per_row) return;
+  const int row = (int)(i / per_row), c = (int)(i % per_row) * 4;
+  f32x4_e acc = *(const f32x4_e*)(part + (int64_t)row * N + c);
+  for (int z = 1; z < nsplit; ++z) {
+    const f32x4_e v = *(const f32x4_e*)(part + (int64_t)z * stride + (int64_t)row * N + c);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  const f32x4_e b = bias ? *(const f32x4_e*)(bias + c) : f32x4_e{0.f, 0.f, 0.f, 0.f};
+  const f32x4_e g = *(const f32x4_e*)(gate + (int64_t)(row / ntok) * gate_bstride + c);
+  f32x4_e xv = *(const f32x4_e*)(x + (int64_t)row * N + c);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xv[j] += g[j] * (acc[j] + b[j]);
+  *(f32x4_e*)(x + (int64_t)row * N + c) = xv;
+}
+hipError_t launch_splitk_resid_finish(const float* part, int nsplit, int64_t stride, const float* bias, const float* gate,
+                                      int64_t gate_bstride, int ntok, float* x, int M, int N, hipStream_t s) {
+  if (N % 4 != 0 || nsplit < 1) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)M * (N / 4);
+  hipLaunchKernelGGL(splitk_resid_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nsplit, stride, bias,
+                     gate, gate_bstride, ntok, x, M, N);
+  return hipGetLastError();
+}

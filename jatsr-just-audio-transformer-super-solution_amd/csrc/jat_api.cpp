@@ -29,9 +29,14 @@ int jat_fail(int code, const char* fmt, ...) {
 struct Workspace {
   bf16_t *a_patch, *h_patch, *xn, *q, *k, *vt, *ao, *hm, *t_silu;
   float *x, *mod, *e_sin, *t_h, *t_emb, *part;
+  float* kpart;   // split-K partials of the fc2 GEMM when M is too small to fill the chip (nullptr for large M)
   int npad;
   size_t vt_bytes, total;
 };
+
+// Small-M inference (the reference's own B = 1 chunk loop gives M = 690 rows with CFG; a file's short last chunk M = 240):
+// the K = 5120 fc2 GEMM has a few dozen tiles x 80 K-steps — split K over otherwise idle CUs, finish in fixed order.
+static constexpr int kSplitMaxRows = 2304, kSplitMax = 8;
 
 static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
   Workspace w;
@@ -59,6 +64,7 @@ static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
   w.t_emb = (float*)take((size_t)B * m->D * 4);
   w.t_silu = (bf16_t*)take((size_t)B * m->D * 2);
   w.part = (float*)take(M * 32 * 4);  // row partial sums of x^2 (norm folding), <= 32 wave column tiles
+  w.kpart = M <= kSplitMaxRows ? (float*)take((size_t)kSplitMax * M * m->D * 4) : nullptr;
   w.total = off;
   return w;
 }
@@ -418,7 +424,23 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
       e.fold_out = w.xn; e.fold_part = w.part;
       e.fold_g = (l + 1 < m->depth) ? f->g + ((int64_t)(l + 1) * 2) * D : f->g_final;
     }
-    JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_RESID, e, s));
+    int split = 1;
+    if (w.kpart && !f && m->mlp >= 2048 && m->variants[G_FC2] < 0) {
+      int bm, bn;
+      const int v = pick_variant(M, D);
+      gemm_variant_tile(v, &bm, &bn);
+      const int tiles = ((M + bm - 1) / bm) * (D / bn), slots = (v == 18 || v == 20 || v == 27) ? 512 : 256;
+      split = slots / tiles < kSplitMax ? slots / tiles : kSplitMax;
+      while (split > 1 && (m->mlp / 64) % split != 0) --split;
+    }
+    if (split > 1) {
+      GemmArgs p{};
+      p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D;
+      JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_F32, p, s));
+      KCHK(launch_splitk_resid_finish(w.kpart, split, (int64_t)M * D, L.b2, mod_l + 5 * D, bstride, ntok, w.x, M, D, s));
+    } else {
+      JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_RESID, e, s));
+    }
   }
   return JAT_OK;
 }
