@@ -142,7 +142,7 @@ hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, con
                            int64_t dmod_bstride, float* dw, int B, int D, int ntok, int mode, hipStream_t s);
 hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
                                 const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
-                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, hipStream_t s);
+                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, float* dkv_part, hipStream_t s);
 hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
                            float loss_scale, hipStream_t s);
 // v3mod2 loss (MSE + lw * (fw*freq + mw*ms + cw*cons)): dpred = d(loss * loss_scale)/d pred, out6 = {total, mse, freq, ms,

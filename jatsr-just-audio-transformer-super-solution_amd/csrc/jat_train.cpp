@@ -63,6 +63,7 @@ struct jat_trainer {
   float2* tw = nullptr;                // [T] twiddles
   float *ll_part = nullptr, *terms = nullptr;
   float* dw_split = nullptr;           // split-K partials of the small dW GEMMs
+  float* dkv_part = nullptr;           // per-query-head fp32 partials of dK / dV (attention backward)
   int64_t split4_area = 0, split2_area = 0;
 };
 
@@ -257,7 +258,7 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
     JCHK(input_grad(tr, tr->dy, D, L.woT, D, tr->dao, s));
     JCHK(weight_grad(tr, tr->dy, D, L.ao, D, G + L.o_o, nullptr, s));
     KCHK(launch_attention_bwd(L.q, L.k, L.vt, L.ao, tr->dao, L.lse, tr->delta, tr->dqkv, m->rope_cos, m->rope_sin, B, ntok,
-                              m->Hq, m->Hkv, tr->npad, site(tr, l, 0), s));
+                              m->Hq, m->Hkv, tr->npad, site(tr, l, 0), tr->dkv_part, s));
     JCHK(input_grad(tr, tr->dqkv, Nqkv, L.wqkvT, D, tr->dxn, s));
     JCHK(weight_grad(tr, tr->dqkv, Nqkv, L.xn1, D, tr->dwqkv, nullptr, s));
     KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, s));
@@ -415,6 +416,7 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     tr->tw = (float2*)take((size_t)T * sizeof(float2));
     tr->ll_part = (float*)take((size_t)B * m->Cin * 8 * 4);
     tr->delta = (float*)take((size_t)B * m->Hq * ntok * 4);
+    tr->dkv_part = (float*)take((size_t)B * m->Hq * ntok * 128 * 4);
     tr->dwqkv = (float*)take((size_t)Nqkv * D * 4);
     tr->dt_emb = (float*)take((size_t)B * D * 4);
     tr->du1 = (float*)take((size_t)B * D * 4);

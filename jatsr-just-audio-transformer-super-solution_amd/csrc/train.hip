@@ -418,6 +418,10 @@ struct AttnBwdArgs {
   int B, N, Hq, Hkv, npad, D, kvD;
   float scale_log2e, scale;
   DropSpec drop;   // attention-probability dropout (:175): element ((b*Hq + h)*N + i)*N + j
+  // dK/dV: the G query heads of a KV group may be spread over `hsplit` blocks (more, shorter blocks: better balance);
+  // each then writes an fp32 partial [(b*Hkv + g)*hsplit + part][N][128] (dK | dV) summed by attn_dkv_reduce_kernel
+  float* dkv_part;
+  int hsplit;
 };
 
 // 64 x 64 bf16 tile staging, split in a global-load half (issued one iteration ahead) and an LDS-store half.
@@ -514,19 +518,21 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
   __shared__ __attribute__((aligned(16))) unsigned short sK[64][AP], sVt[64][AP], sQ[64][AP], sDO[64][AP], sPT[64][AP],
       sDST[64][AP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-  const int jb = blockIdx.x, g = blockIdx.y, b = blockIdx.z, N = p.N, G = p.Hq / p.Hkv;
+  const int jb = blockIdx.x, b = blockIdx.z, N = p.N, G = p.Hq / p.Hkv;
+  const int g = blockIdx.y / p.hsplit, part = blockIdx.y - g * p.hsplit;
+  const int h_lo = part * G / p.hsplit, h_hi = (part + 1) * G / p.hsplit;   // this block's query heads of group g
   const int j0 = jb * 64;
   tile_store(tile_load(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, tid), sK, tid);
   tile_store(tile_load(p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad + j0, p.npad, 0, 64, tid), sVt, tid);
   f32x4_t dk[4], dv[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) dk[nt] = dv[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int nib = (N + 63) / 64, niter = G * nib;
+  const int nib = (N + 63) / 64, niter = (h_hi - h_lo) * nib;
   const bf16_t* qb = p.q + (int64_t)b * N * p.ldq;
   const bf16_t* dob = p.dout + (int64_t)b * N * p.ldq;
-  TileRegs rq = tile_load(qb + (g * G) * 64, p.ldq, 0, N, tid), rdo = tile_load(dob + (g * G) * 64, p.ldq, 0, N, tid);
+  TileRegs rq = tile_load(qb + (g * G + h_lo) * 64, p.ldq, 0, N, tid), rdo = tile_load(dob + (g * G + h_lo) * 64, p.ldq, 0, N, tid);
   for (int it = 0; it < niter; ++it) {
-    const int hh = it / nib, ib = it - hh * nib;
+    const int hh = h_lo + it / nib, ib = it - (it / nib) * nib;
     {
       const int h = g * G + hh;
       const float* lse = p.lse + ((int64_t)b * p.Hq + h) * N;
@@ -544,7 +550,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
       }
       __syncthreads();
       if (it + 1 < niter) {   // next (head, query block): global loads fly under this iteration's MFMAs
-        const int hn = (it + 1) / nib, ibn = (it + 1) - hn * nib;
+        const int hn = h_lo + (it + 1) / nib, ibn = (it + 1) - ((it + 1) / nib) * nib;
         rq = tile_load(qb + (g * G + hn) * 64, p.ldq, ibn * 64, N, tid);
         rdo = tile_load(dob + (g * G + hn) * 64, p.ldq, ibn * 64, N, tid);
       }
@@ -584,9 +590,49 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
     }
   }
   const int nrows = min(16, N - (j0 + wave * 16));
+  if (p.hsplit > 1) {   // fp32 partial of this block's heads; RoPE^T, the head sum and the bf16 cast happen in the reduce
+    float* pb = p.dkv_part + ((int64_t)((b * p.Hkv + g) * p.hsplit + part) * N) * 128;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = fg * 4 + r;
+        if (lr < nrows) {
+          float* rowp = pb + (int64_t)(j0 + wave * 16 + lr) * 128 + nt * 16 + fr;
+          rowp[0] = dk[nt][r];
+          rowp[64] = dv[nt][r];
+        }
+      }
+    return;
+  }
   bf16_t* base = p.dqkv + (int64_t)b * N * p.ldg;
   store_strip(dk, base + p.D + g * 64, p.ldg, j0 + wave * 16, nrows, j0 + wave * 16, p.rope_cos, p.rope_sin, lane);
   store_strip(dv, base + p.D + p.kvD + g * 64, p.ldg, j0 + wave * 16, nrows, 0, nullptr, nullptr, lane);
+}
+
+// dK / dV of (b, g): sum of the hsplit fp32 partials in fixed order, inverse RoPE on dK (interleaved pairs), bf16 into dqkv
+__global__ void __launch_bounds__(256) attn_dkv_reduce_kernel(const AttnBwdArgs p) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (b, g, j, pair): 64 pairs per row (32 dK + 32 dV)
+  const int64_t total = (int64_t)p.B * p.Hkv * p.N * 64;
+  if (idx >= total) return;
+  const int pr = (int)(idx & 63);
+  const int64_t rowi = idx >> 6;                 // (b*Hkv + g)*N + j
+  const int j = (int)(rowi % p.N);
+  const int64_t bg = rowi / p.N;
+  const int g = (int)(bg % p.Hkv), b = (int)(bg / p.Hkv);
+  float v0 = 0.f, v1 = 0.f;
+  for (int z = 0; z < p.hsplit; ++z) {
+    const float* src = p.dkv_part + ((bg * p.hsplit + z) * p.N + j) * 128 + pr * 2;
+    v0 += src[0]; v1 += src[1];
+  }
+  bf16_t* dst = p.dqkv + ((int64_t)b * p.N + j) * p.ldg + p.D;
+  if (pr < 32) {   // dK pair (2d', 2d'+1): x0' = c x0 + s x1, x1' = c x1 - s x0
+    const float c = p.rope_cos[min(j, 2047) * 32 + pr], sn = p.rope_sin[min(j, 2047) * 32 + pr];
+    const float o0 = c * v0 + sn * v1, o1 = c * v1 - sn * v0;
+    *(unsigned*)(dst + g * 64 + pr * 2) = (unsigned)f2bf_t(o0) | ((unsigned)f2bf_t(o1) << 16);
+  } else {
+    *(unsigned*)(dst + p.kvD + g * 64 + (pr - 32) * 2) = (unsigned)f2bf_t(v0) | ((unsigned)f2bf_t(v1) << 16);
+  }
 }
 
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
@@ -675,7 +721,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 
 hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
                                 const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
-                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, hipStream_t s) {
+                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, float* dkv_part, hipStream_t s) {
   if (Hq % Hkv != 0 || npad % 64 != 0 || npad < N || N > 2048) return hipErrorInvalidValue;
   AttnBwdArgs a;
   a.drop = drop;
@@ -687,7 +733,14 @@ hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* 
   const int64_t nd = (int64_t)B * N * Hq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, o, dout, (int64_t)a.D, delta, B, N, Hq);
   const int nb = (N + 63) / 64;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, Hkv, B), dim3(256), 0, s, a);
+  // dkv_part (B*Hq*N*128 floats) given: one query head per block, partials reduced afterwards
+  a.dkv_part = dkv_part;
+  a.hsplit = (dkv_part && Hq > Hkv) ? Hq / Hkv : 1;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, Hkv * a.hsplit, B), dim3(256), 0, s, a);
+  if (a.hsplit > 1) {
+    const int64_t nr = (int64_t)B * Hkv * N * 64;
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s, a);
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb, Hq, B), dim3(256), 0, s, a);
   return hipGetLastError();
 }
