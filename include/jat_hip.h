@@ -163,7 +163,8 @@ int jat_trainer_prepare(jat_trainer* tr, const float* hr_norm, float* cond, cons
 int jat_trainer_fwd_bwd(jat_trainer* tr, const float* z_t, const float* t, const float* x_cond, const float* target,
                         const float* cond_clean, float loss_scale, uint64_t rng_seed, float* loss_out, float* x_pred_out,
                         void* stream);
-/* grad_norm_out (device, 1 float, nullable) = L2 norm of the loss-SCALED gradients (divide by loss_scale).  A
+/* grads_flat is read, not modified (clip_grad_norm_'s in-place scaling of .grad is not reproduced: nothing reads it).
+ * grad_norm_out (device, 1 float, nullable) = L2 norm of the loss-SCALED gradients (divide by loss_scale).  A
  * non-finite norm leaves parameters and moments untouched (GradScaler.step).  `step` is 1-based (bias correction). */
 int jat_trainer_optim(jat_trainer* tr, float lr, float beta1, float beta2, float eps, float weight_decay,
                       float max_grad_norm, float loss_scale, int32_t step, float* grad_norm_out, void* stream);

@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(256) sqsum_kernel(const float* __restrict__ g,
 }
 // norm2[0] = sum g^2 of the SCALED gradients, norm2[1] = its square root.  inv_scale undoes the loss scaling.
 // A non-finite norm skips the update (GradScaler.step semantics, train_ddp_v3m2.py:618).
-__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, const float* __restrict__ norm2,
                                                     float inv_scale, float max_norm, float lr, float beta1, float beta2,
                                                     float eps, float wd, float bc1, float bc2_sqrt) {
@@ -818,15 +818,14 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float
     f32x4_t pp = *(const f32x4_t*)(p + i), gg = *(const f32x4_t*)(g + i), mm = *(const f32x4_t*)(m + i), vv = *(const f32x4_t*)(v + i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float gr = gg[j] * coef;
-      gg[j] = gr;
+      const float gr = gg[j] * coef;   // unscaled, clipped gradient (not written back: nothing reads it after the step)
       pp[j] *= 1.0f - lr * wd;
       mm[j] = beta1 * mm[j] + (1.0f - beta1) * gr;
       vv[j] = beta2 * vv[j] + (1.0f - beta2) * gr * gr;
       const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
       pp[j] -= (lr / bc1) * (mm[j] / denom);
     }
-    *(f32x4_t*)(p + i) = pp; *(f32x4_t*)(g + i) = gg; *(f32x4_t*)(m + i) = mm; *(f32x4_t*)(v + i) = vv;
+    *(f32x4_t*)(p + i) = pp; *(f32x4_t*)(m + i) = mm; *(f32x4_t*)(v + i) = vv;
   }
 }
 hipError_t launch_grad_sqsum(const float* g, int64_t n, float* part, float* norm2, hipStream_t s) {
