@@ -454,6 +454,42 @@ __device__ __forceinline__ void strip_mma(unsigned short (*X)[AP], int xr0, unsi
     }
   }
 }
+// A row-read-only image without padding: [64][64] bf16 (128-B rows), 16-B chunks XOR-swizzled by (row & 7) — conflict-free
+// ds_read_b128 like the GEMM's tiles, and 1 KiB smaller than the padded form (what lets three dK/dV blocks share a CU).
+__device__ __forceinline__ void tile_store_swz(const TileRegs& t, unsigned short (*dst)[64], int tid) {
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass * 32 + (tid >> 3), ch = tid & 7;
+    *(u32x4_t*)&dst[r][(ch ^ (r & 7)) * 8] = t.v[pass];
+  }
+}
+// acc[nt] += X[xr0 + m][k] * Ysw[16 nt + n][k]   with Ysw a swizzled unpadded image
+__device__ __forceinline__ void strip_mma_swzY(unsigned short (*X)[AP], int xr0, unsigned short (*Ysw)[64], f32x4_t* acc, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8_t a = *(const bf16x8_t*)&X[xr0 + fr][ks * 32 + fg * 8];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int r = nt * 16 + fr;
+      const bf16x8_t bb = *(const bf16x8_t*)&Ysw[r][((ks * 4 + fg) ^ (r & 7)) * 8];
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nt], 0, 0, 0);
+    }
+  }
+}
+// acc[nt] += Xsw[xr0 + m][k] * Yt[k][16 nt + n]      (first operand: swizzled unpadded image; second stored k-major)
+__device__ __forceinline__ bf16x8_t tr_frag(unsigned short (*img)[AP], int k0, int c0, int lane);
+__device__ __forceinline__ void strip_mma_tr_swzX(unsigned short (*Xsw)[64], int xr0, unsigned short (*Yt)[AP], f32x4_t* acc,
+                                                  int lane) {
+  const int fr = lane & 15, fg = lane >> 4, r = xr0 + fr;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8_t a = *(const bf16x8_t*)&Xsw[r][((ks * 4 + fg) ^ (r & 7)) * 8];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, tr_frag(Yt, ks * 32, nt * 16, lane), acc[nt], 0, 0, 0);
+  }
+}
 // Operand fragment of a TRANSPOSED image: element j of lane (fg, fr) = img[k0 + 8 fg + j][c0 + fr], j = 0..7, by two
 // ds_read_b64_tr_b16 (each hands a 16-lane group a 4-row x 16-column block column-major; lane 4q+p supplies the
 // address of row q, columns 4p..4p+3).  Needs all 64 lanes active.
@@ -512,17 +548,17 @@ __device__ __forceinline__ void store_strip(const f32x4_t* acc, bf16_t* __restri
     }
 }
 
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) {
+__global__ void __launch_bounds__(256, 3) attn_bwd_dkv_kernel(const AttnBwdArgs p) {
   // K [j][d], V^T [d][j] (as stored), Q [i][d], dO [i][d] row-major; P^T, dS^T [j][i].  The products that contract over
   // the ROW index of an image (dP over d of V^T, dV / dK over i of dO / Q) read it with ds_read_b64_tr_b16.
-  __shared__ __attribute__((aligned(16))) unsigned short sK[64][AP], sVt[64][AP], sQ[64][AP], sDO[64][AP], sPT[64][AP],
-      sDST[64][AP];
+  __shared__ __attribute__((aligned(16))) unsigned short sK[64][64], sVt[64][AP], sQ[64][AP], sDO[64][AP], sPT[64][64],
+      sDST[64][64];   // 52 224 B: three blocks per CU (K, P^T, dS^T are only ever read by rows: unpadded + swizzled)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int jb = blockIdx.x, b = blockIdx.z, N = p.N, G = p.Hq / p.Hkv;
   const int g = blockIdx.y / p.hsplit, part = blockIdx.y - g * p.hsplit;
   const int h_lo = part * G / p.hsplit, h_hi = (part + 1) * G / p.hsplit;   // this block's query heads of group g
   const int j0 = jb * 64;
-  tile_store(tile_load(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, tid), sK, tid);
+  tile_store_swz(tile_load(p.k + (int64_t)b * N * p.ldk + g * 64, p.ldk, j0, N, tid), sK, tid);
   tile_store(tile_load(p.vt + ((int64_t)(b * p.Hkv + g) * 64) * p.npad + j0, p.npad, 0, 64, tid), sVt, tid);
   f32x4_t dk[4], dv[4];
 #pragma unroll
@@ -557,7 +593,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
       f32x4_t sacc[4], pacc[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) sacc[nt] = pacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      strip_mma(sQ, wave * 16, sK, sacc, lane);        // S[i][j]  = sum_d Q[i][d] K[j][d]
+      strip_mma_swzY(sQ, wave * 16, sK, sacc, lane);   // S[i][j]  = sum_d Q[i][d] K[j][d]
       strip_mma_tr(sDO, wave * 16, sVt, pacc, lane);   // dP[i][j] = sum_d dO[i][d] V^T[d][j]
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -581,12 +617,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs p) 
         a[1] = (unsigned)f2bf_t(pr[2]) | ((unsigned)f2bf_t(pr[3]) << 16);
         d[0] = (unsigned)f2bf_t(ds[0]) | ((unsigned)f2bf_t(ds[1]) << 16);
         d[1] = (unsigned)f2bf_t(ds[2]) | ((unsigned)f2bf_t(ds[3]) << 16);
-        *(u32x2_t*)&sPT[nt * 16 + fr][wave * 16 + fg * 4] = a;    // P^T[j][i]
-        *(u32x2_t*)&sDST[nt * 16 + fr][wave * 16 + fg * 4] = d;   // dS^T[j][i]
+        {
+          const int row = nt * 16 + fr, col = wave * 16 + fg * 4;   // 8-byte store inside the swizzled 16-byte chunk
+          const int sw = (((col >> 3) ^ (row & 7)) << 3) + (col & 7);
+          *(u32x2_t*)&sPT[row][sw] = a;    // P^T[j][i]
+          *(u32x2_t*)&sDST[row][sw] = d;   // dS^T[j][i]
+        }
       }
       __syncthreads();
-      strip_mma_tr(sPT, wave * 16, sDO, dv, lane);   // dV[j][d] += sum_i P^T[j][i] dO[i][d]
-      strip_mma_tr(sDST, wave * 16, sQ, dk, lane);   // dK[j][d] += sum_i dS^T[j][i] Q[i][d]
+      strip_mma_tr_swzX(sPT, wave * 16, sDO, dv, lane);   // dV[j][d] += sum_i P^T[j][i] dO[i][d]
+      strip_mma_tr_swzX(sDST, wave * 16, sQ, dk, lane);   // dK[j][d] += sum_i dS^T[j][i] Q[i][d]
     }
   }
   const int nrows = min(16, N - (j0 + wave * 16));
