@@ -372,6 +372,18 @@ struct Fold {
   const float *g, *bq, *bf, *g_final;
 };
 
+// K-slices for a gated-residual GEMM [M, D] = A[M, K] W^T whose tiles do not fill the chip (small-M inference), 1 = none
+static int resid_split(const jat_model* m, const Workspace& w, int site, int M, int K, bool folding) {
+  if (!w.kpart || folding || K < 1024 || m->variants[site] >= 0) return 1;
+  int bm, bn;
+  const int v = pick_variant(M, m->D);
+  gemm_variant_tile(v, &bm, &bn);
+  const int tiles = ((M + bm - 1) / bm) * (m->D / bn), slots = (v == 18 || v == 20 || v == 27) ? 512 : 256;
+  int split = slots / tiles < kSplitMax ? slots / tiles : kSplitMax;
+  while (split > 1 && ((K / 64) % split != 0 || K / split < 256)) --split;   // >= 4 K-tiles per slice
+  return split > 1 ? split : 1;
+}
+
 // one DiTBlock_GQA on the residual stream w.x  (jat_audiosr_v3.py:284-308); mod_l = this layer's 6D row of batch 0
 static int run_block(const jat_model* m, const Workspace& w, int l, int B, int ntok, const float* mod_l,
                      int64_t bstride, hipStream_t s, const Fold* f = nullptr) {
@@ -408,7 +420,15 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
     if (f) { e.fold_out = w.xn; e.fold_g = f->g + ((int64_t)l * 2 + 1) * D; e.fold_part = w.part; }
-    JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_RESID, e, s));
+    const int split = resid_split(m, w, G_OUT, M, D, f != nullptr);
+    if (split > 1) {
+      GemmArgs p{};
+      p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D;
+      JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_F32, p, s));
+      KCHK(launch_splitk_resid_finish(w.kpart, split, (int64_t)M * D, nullptr, mod_l + 2 * D, bstride, ntok, w.x, M, D, s));
+    } else {
+      JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_RESID, e, s));
+    }
   }
   if (!f) KCHK(launch_norm_modulate(w.x, L.norm2, mod_l + 3 * D, mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
@@ -424,15 +444,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
       e.fold_out = w.xn; e.fold_part = w.part;
       e.fold_g = (l + 1 < m->depth) ? f->g + ((int64_t)(l + 1) * 2) * D : f->g_final;
     }
-    int split = 1;
-    if (w.kpart && !f && m->mlp >= 2048 && m->variants[G_FC2] < 0) {
-      int bm, bn;
-      const int v = pick_variant(M, D);
-      gemm_variant_tile(v, &bm, &bn);
-      const int tiles = ((M + bm - 1) / bm) * (D / bn), slots = (v == 18 || v == 20 || v == 27) ? 512 : 256;
-      split = slots / tiles < kSplitMax ? slots / tiles : kSplitMax;
-      while (split > 1 && (m->mlp / 64) % split != 0) --split;
-    }
+    const int split = resid_split(m, w, G_FC2, M, m->mlp, f != nullptr);
     if (split > 1) {
       GemmArgs p{};
       p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D;
