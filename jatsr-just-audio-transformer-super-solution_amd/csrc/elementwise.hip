@@ -330,6 +330,36 @@ hipError_t launch_cast_bf16_rope_rows(const float* in, bf16_t* out, int rows, in
   return hipGetLastError();
 }
 
+// ---- weight folding (sampler creation only): out[r][c] = bf16(in[src(r)][c] * g[c]) -------------------------------------
+// RMSNorm + adaLN modulation commute with the following Linear when every row shares the modulation (the sampler: one t
+// per step, infer_test_v3m2.py:150):  (x * rstd * w * (1 + scale) + shift) @ W^T = rstd * (x @ (W diag(g))^T) + shift @ W^T,
+// g = w * (1 + scale).  rope != 0: rows pair-interleaved per 64-row head as launch_cast_bf16_rope_rows does.
+__global__ void fold_weight_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
+                                   bf16_t* __restrict__ out, int rows, int cols, int rope) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  int src = r;
+  if (rope) {
+    const int h = r >> 6, q = r & 63;
+    src = (h << 6) + (q >> 1) + ((q & 1) << 5);
+  }
+  const float4 v = *(const float4*)(in + (int64_t)src * cols + c);
+  float4 g = *(const float4*)(w + c);
+  if (scale) {
+    const float4 sc = *(const float4*)(scale + c);
+    g.x *= 1.0f + sc.x; g.y *= 1.0f + sc.y; g.z *= 1.0f + sc.z; g.w *= 1.0f + sc.w;
+  }
+  *(uint2*)(out + i) = pack4_e(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+}
+hipError_t launch_fold_weight(const float* in, const float* w, const float* scale, bf16_t* out, int rows, int cols, int rope,
+                              hipStream_t s) {
+  if ((rope && rows % 64 != 0) || cols % 4 != 0) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(fold_weight_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, in, w, scale, out, rows, cols, rope);
+  return hipGetLastError();
+}
+
 // ---- norm-folding table helpers (sampler creation only) ---------------------------------------------------------
 __global__ void fold_scale_kernel(const float* __restrict__ w, const float* __restrict__ scale, int64_t in_stride,
                                   float* __restrict__ out, int64_t out_stride, int rows, int cols) {

@@ -39,19 +39,20 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   r.y = (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16);
   return r;
 }
-// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 output rounding): nn.GELU() erf form.
+// GELU (erf form, nn.GELU() default: jat_audiosr_v3.py:223,268) as x * sigmoid(x * P(x^2)), P a cubic in x^2 fitted to
+// logit(Phi(x)) on |x| <= 7 (minimax on the absolute error; outside, x is clamped inside P only, where sigmoid is 0 or 1
+// to 1e-10).  |gelu_fast - gelu| <= 9.5e-5 for every x (tests/test_host_cpu.py checks the same expression in numpy
+// against scipy's erf), i.e. <= 1/20 of the bf16 ulp the result is rounded to at |gelu| >= 0.25.  8 VALU issues (two
+// transcendental) instead of 20 for Abramowitz-Stegun 7.1.26: the epilogue of the fc1 GEMM is VALU-bound, not store-
+// bound (140 values per lane per 224 x 320 tile).
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  float poly = 1.061405429f;
-  poly = poly * t - 1.453152027f;
-  poly = poly * t + 1.421413741f;
-  poly = poly * t - 0.284496736f;
-  poly = poly * t + 0.254829592f;
-  poly *= t;
-  const float e = 1.0f - poly * __expf(-z * z);
-  const float erfv = x < 0.f ? -e : e;
-  return 0.5f * x * (1.0f + erfv);
+  const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+  const float x2 = xc * xc;
+  float p = fmaf(x2, 7.21813398e-06f, 9.30041738e-04f);     // coefficients pre-multiplied by -log2(e)
+  p = fmaf(p, x2, -1.06125564e-01f);
+  p = fmaf(p, x2, -2.30169559e+00f);
+  const float e = __builtin_amdgcn_exp2f(p * xc);           // exp(-x P(x^2))
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // consumer side of the norm folding: 1/rms of row m of the A operand from the producer's partial sums (fixed order)
@@ -92,10 +93,10 @@ __device__ __forceinline__ void rows_rstd(const GemmArgs& p, int row0, int lane,
     rstd[i] = rsqrtf(sq * invk + 1e-6f);
   }
 }
-// producer side: A'[m][n..n+3] = bf16(x * g[b][n..n+3]); this chunk's sum of squares goes back into its slab slot
+// producer side: A'[m][n..n+3] = bf16(x) (the norm weight and the adaLN scale live in the consumer's folded weights);
+// this chunk's sum of squares goes back into its slab slot
 __device__ __forceinline__ void fold_emit(const GemmArgs& p, char* slot, float4 x, int m, int n, int b) {
-  const float4 g = *(const float4*)(p.fold_g + (int64_t)b * p.fold_g_bstride + n);
-  *(uint2*)(p.fold_out + (int64_t)m * p.ldo + n) = pack4(x.x * g.x, x.y * g.y, x.z * g.z, x.w * g.w);
+  *(uint2*)(p.fold_out + (int64_t)m * p.ldo + n) = pack4(x.x, x.y, x.z, x.w);
   *(float*)slot = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
 }
 
@@ -103,7 +104,7 @@ __device__ __forceinline__ void fold_emit(const GemmArgs& p, char* slot, float4 
 // register allocation accordingly (2nd launch-bounds argument = waves per SIMD).
 // PIPE 6 adds 4 DMA-only waves (one per SIMD) to the 8 MFMA waves: 768 threads, three waves per SIMD.
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
-__global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
+__global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
     gemm_bf16_kernel(const GemmArgs p_in) {
   GemmArgs p = p_in;
   if (p.ksplit > 1) {   // split-K slice of this block (uniform): shift the operands along K and the output to its partial
@@ -456,6 +457,200 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
       __builtin_amdgcn_s_setprio(0);
       cur = nxt;
     }
+  } else if constexpr (PIPE == 8) {
+    // Quadrant ping-pong (the "8-phase" structure of cdna_hip_programming.md §5, generalised to any TM x TN wave tile and to
+    // uneven halves): the wave tile is cut into an A split (rows: TMa + TMb 16-row MFMA tiles; one part when SPLIT_M is off)
+    // and a B split (columns: TNa + TNb); one PHASE = the fragment reads of ONE part (both k-steps of the K-tile) + one
+    // unit of global->LDS DMA, s_barrier, the MFMAs of one quadrant, s_barrier.  The two waves that share a SIMD (w, w+4)
+    // run ONE barrier apart, so a quadrant's MFMAs always overlap the partner's LDS reads / DMA issue, and a wave holds
+    // one A part + one B part of fragments (<= 56 VGPRs) instead of a double-buffered K-tile (96): a 7 x 5 wave tile
+    // (224 x 320 block, two exact rounds of 256 CUs for M = 7168, N = 5120) fits 256 registers.
+    //   quadrant order (serpentine, one operand part changes per phase):  (A0,B0) (A0,B1) (A1,B1) (A1,B0)
+    //   2 LDS stages (K-tile parity); a part's DMA for K-tile t+2 is issued ONE phase after its last read in K-tile t:
+    //     P1(t): B0(t+1)   P2(t): A0(t+2)   P3(t): B1(t+2)   P4(t): A1(t+2)  + counted vmcnt: K-tile t+1 has landed
+    //   (SPLIT_M off:  P1(t): B1(t+1)   P2(t): A(t+2), B0(t+2) + counted vmcnt.)
+    // Hazards (MI355X_MICROARCH "Two waves per SIMD" item 7; guide "Read a staged buffer one phase AFTER the wait"):
+    //   RAW  every wave's counted vmcnt sits before the first barrier of the K-tile's last phase; the first read of K-tile
+    //        t+1 is after that phase's second barrier (one more barrier for the trailing wave group);
+    //   WAR  fragment reads are retired (lgkmcnt(0)) BEFORE the phase's first barrier, the overwrite is issued after its
+    //        second barrier by either group.
+    static_assert(NW == 8, "quadrant ping-pong needs two waves per SIMD in one block");
+    constexpr bool SPLIT_M = TM * TN > 20;
+    constexpr int TMa = SPLIT_M ? (TM + 1) / 2 : TM, TMb = TM - TMa, TNa = (TN + 1) / 2, TNb = TN - TNa;
+    // DMA units: 8-row pieces of each part, dealt round-robin to the 8 waves (the last pieces are duplicated so that every
+    // wave issues the same number of DMAs per unit: the vmcnt immediates are then compile-time constants)
+    constexpr int PA0 = WM * TMa * 2, PA1 = WM * TMb * 2, PB0 = WN * TNa * 2, PB1 = WN * TNb * 2;
+    constexpr int CA0 = (PA0 + 7) / 8, CA1 = (PA1 + 7) / 8, CB0 = (PB0 + 7) / 8, CB1 = (PB1 + 7) / 8;
+    constexpr int CTILE = CA0 + CA1 + CB0 + CB1;
+    const int grp = wave >> 2;
+    const char* a_base = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* b_base = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    // per-lane byte offsets (32-bit, relative to the tile's first row) and wave-uniform LDS offsets of my pieces
+    unsigned oa0[CA0], oa1[CA1 > 0 ? CA1 : 1], ob0[CB0], ob1[CB1];
+    int la0[CA0], la1[CA1 > 0 ? CA1 : 1], lb0[CB0], lb1[CB1];
+    auto piece_row = [&](int q, int per, int tiles, int first) {   // piece q of a part: per = 2 * tiles-in-part pieces per wave row/col
+      const int w = q / per, in = q - w * per;
+      return w * tiles * 16 + first * 16 + in * 8;
+    };
+#pragma unroll
+    for (int j = 0; j < CA0; ++j) {
+      const int r = piece_row(min(wave + 8 * j, PA0 - 1), TMa * 2, TM, 0);
+      oa0[j] = (unsigned)((min(m0 + r + srow, p.M - 1) - m0) * (int)p.lda * 2 + schunk * 16);
+      la0[j] = r * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < CA1; ++j) {
+      const int r = piece_row(min(wave + 8 * j, PA1 - 1), TMb * 2, TM, TMa);
+      oa1[j] = (unsigned)((min(m0 + r + srow, p.M - 1) - m0) * (int)p.lda * 2 + schunk * 16);
+      la1[j] = r * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < CB0; ++j) {
+      const int r = piece_row(min(wave + 8 * j, PB0 - 1), TNa * 2, TN, 0);
+      ob0[j] = (unsigned)((r + srow) * (int)p.ldw * 2 + schunk * 16);
+      lb0[j] = A_BYTES + r * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < CB1; ++j) {
+      const int r = piece_row(min(wave + 8 * j, PB1 - 1), TNb * 2, TN, TNa);
+      ob1[j] = (unsigned)((r + srow) * (int)p.ldw * 2 + schunk * 16);
+      lb1[j] = A_BYTES + r * 128;
+    }
+    auto dma_a0 = [&](int st, int kt) {
+#pragma unroll
+      for (int j = 0; j < CA0; ++j)
+        __builtin_amdgcn_global_load_lds((const void*)(a_base + kt * 128 + oa0[j]), (lds_ptr_t)(smem + st * STAGE + la0[j]), 16, 0, 0);
+    };
+    auto dma_a1 = [&](int st, int kt) {
+#pragma unroll
+      for (int j = 0; j < CA1; ++j)
+        __builtin_amdgcn_global_load_lds((const void*)(a_base + kt * 128 + oa1[j]), (lds_ptr_t)(smem + st * STAGE + la1[j]), 16, 0, 0);
+    };
+    auto dma_b0 = [&](int st, int kt) {
+#pragma unroll
+      for (int j = 0; j < CB0; ++j)
+        __builtin_amdgcn_global_load_lds((const void*)(b_base + kt * 128 + ob0[j]), (lds_ptr_t)(smem + st * STAGE + lb0[j]), 16, 0, 0);
+    };
+    auto dma_b1 = [&](int st, int kt) {
+#pragma unroll
+      for (int j = 0; j < CB1; ++j)
+        __builtin_amdgcn_global_load_lds((const void*)(b_base + kt * 128 + ob1[j]), (lds_ptr_t)(smem + st * STAGE + lb1[j]), 16, 0, 0);
+    };
+    bf16x8 fa[2][TMa], fb[2][TNa];
+    auto rd_a = [&](int st, int i0, int cnt) {
+      const char* sA = smem + st * STAGE + a_row_off + i0 * 2048;
+#pragma unroll
+      for (int i = 0; i < TMa; ++i)
+        if (i < cnt) {
+          fa[0][i] = *(const bf16x8*)(sA + i * 2048 + coff0);
+          fa[1][i] = *(const bf16x8*)(sA + i * 2048 + coff1);
+        }
+    };
+    auto rd_b = [&](int st, int j0, int cnt) {
+      const char* sB = smem + st * STAGE + A_BYTES + b_row_off + j0 * 2048;
+#pragma unroll
+      for (int j = 0; j < TNa; ++j)
+        if (j < cnt) {
+          fb[0][j] = *(const bf16x8*)(sB + j * 2048 + coff0);
+          fb[1][j] = *(const bf16x8*)(sB + j * 2048 + coff1);
+        }
+    };
+#define JAT_Q(I0, IC, J0, JC)                                                                                   \
+  if (!abl_mma) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+  _Pragma("unroll") for (int i = 0; i < (IC); ++i)                                                              \
+  _Pragma("unroll") for (int j = 0; j < (JC); ++j)                                                              \
+    acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[(I0) + i][(J0) + j], 0, 0, 0);
+#define JAT_LOAD_END()                              \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0);                \
+  __builtin_amdgcn_s_barrier();                     \
+  __builtin_amdgcn_s_setprio(1);
+#define JAT_MMA_END()                 \
+  __builtin_amdgcn_s_setprio(0);      \
+  __builtin_amdgcn_sched_barrier(0);  \
+  __builtin_amdgcn_s_barrier();
+    // prologue: K-tiles 0 and 1 in flight, tile 0 landed
+    dma_a0(0, 0); dma_b0(0, 0); dma_b1(0, 0); dma_a1(0, 0);
+    if (nk > 1) {
+      dma_a0(1, 1); dma_b0(1, 1); dma_b1(1, 1); dma_a1(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTILE) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+#ifdef JAT_DEV_VARIANTS   // timing ablations (wrong results): dbg bit 1: no DMA after the prologue, bit 2: no fragment reads
+    const bool abl_dma = p.dbg & 2, abl_rd = p.dbg & 4, abl_mma = p.dbg & 8;   // after K-tile 0, bit 3: no MFMAs
+#else
+    constexpr bool abl_dma = false, abl_rd = false, abl_mma = false;
+#endif
+    auto ktile = [&](int t, int st) {
+      const bool more2 = t + 2 < nk && !abl_dma;
+      const bool more1 = t >= 1 && t + 1 < nk && !abl_dma;
+      const bool rd = !abl_rd || t == 0;
+      if constexpr (SPLIT_M) {
+        // P1 (A0, B0)
+        if (rd) rd_b(st, 0, TNa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rd) rd_a(st, 0, TMa);
+        if (more1) dma_b0(st ^ 1, t + 1);
+        JAT_LOAD_END()
+        JAT_Q(0, TMa, 0, TNa)
+        JAT_MMA_END()
+        // P2 (A0, B1)
+        if (rd) rd_b(st, TNa, TNb);
+        if (more2) dma_a0(st, t + 2);
+        JAT_LOAD_END()
+        JAT_Q(0, TMa, TNa, TNb)
+        JAT_MMA_END()
+        // P3 (A1, B1)
+        if (rd) rd_a(st, TMa, TMb);
+        if (more2) dma_b1(st, t + 2);
+        JAT_LOAD_END()
+        JAT_Q(TMa, TMb, TNa, TNb)
+        JAT_MMA_END()
+        // P4 (A1, B0)
+        if (rd) rd_b(st, 0, TNa);
+        if (more2) {
+          dma_a1(st, t + 2);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA0 + CB1 + CA1) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        JAT_LOAD_END()
+        JAT_Q(TMa, TMb, 0, TNa)
+        JAT_MMA_END()
+      } else {
+        // P1 (A, B0)
+        if (rd) rd_b(st, 0, TNa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rd) rd_a(st, 0, TMa);
+        if (more1) dma_b1(st ^ 1, t + 1);
+        JAT_LOAD_END()
+        JAT_Q(0, TMa, 0, TNa)
+        JAT_MMA_END()
+        // P2 (A, B1)
+        if (rd) rd_b(st, TNa, TNb);
+        if (more2) {
+          dma_a0(st, t + 2);
+          dma_b0(st, t + 2);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA0 + CB0) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        JAT_LOAD_END()
+        JAT_Q(0, TMa, TNa, TNb)
+        JAT_MMA_END()
+      }
+    };
+    for (int t = 0; t < nk; t += 2) {
+      ktile(t, 0);
+      if (t + 1 < nk) ktile(t + 1, 1);
+    }
+#undef JAT_Q
+#undef JAT_LOAD_END
+#undef JAT_MMA_END
+    if (grp == 0) __builtin_amdgcn_s_barrier();
   } else if constexpr (PIPE == 5) {
     // Ping-pong as PIPE 4, but the W pieces of tile kt+2 are issued from inside the MFMA slot (between the two
     // k-steps), so the load slot (fragment reads + A pieces) is no longer the longer of the two slots.
@@ -538,13 +733,13 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
   // reads back 16 B that are CONTIGUOUS along n, so global loads/stores cover whole rows of the wave tile
   // (full 128-B lines) instead of 8-16 B per lane at a row stride.
   if constexpr (CE && EPI <= EPI_RESID) {
-    static_assert(TM % 2 == 0, "coalesced epilogue walks the wave tile 32 rows at a time");
+    // the wave tile is walked 32 rows at a time; an odd TM leaves a 16-row tail group (rows >= grows are skipped)
     constexpr bool OUT32 = (EPI == EPI_F32 || EPI == EPI_RESID);
     constexpr int EB = OUT32 ? 4 : 2;        // bytes per output element
     constexpr int EPC = 16 / EB;             // elements per 16-B chunk
     constexpr int RS = TN * 16 * EB + 16;    // padded LDS row stride (bytes)
     constexpr int CPR = TN * 16 / EPC;       // chunks per row
-    constexpr int NCH = 32 * CPR / 64;       // chunks per lane per 32-row group
+    constexpr int NCH = (32 * CPR + 63) / 64;  // chunks per lane per 32-row group
     static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
     __builtin_amdgcn_s_barrier();             // every wave is done reading the staging buffers
     if (p.dbg & 1) return;
@@ -558,12 +753,13 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
     const int npass = (EPI == EPI_BF16_GELU && p.dual_rows > 0) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass)
 #pragma unroll
-    for (int ig = 0; ig < TM / 2; ++ig) {
+    for (int ig = 0; ig < (TM + 1) / 2; ++ig) {
+      const int grows = (2 * ig + 1 < TM) ? 32 : 16;   // folds: ig is an unrolled constant
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          f32x4 v = acc[2 * ig + ii][j] * rstd_rows[2 * ig + ii];
+        for (int j = 0; j < TN; ++j) if (2 * ig + ii < TM) {
+          f32x4 v = acc[2 * ig + ii < TM ? 2 * ig + ii : 0][j] * rstd_rows[2 * ig + ii < TM ? 2 * ig + ii : 0];
           v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w;
           if constexpr (EPI == EPI_BF16_GELU) {
             if (npass == 2 && pass == 0) {
@@ -593,7 +789,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
       if constexpr (EPI == EPI_RESID) {
 #pragma unroll
         for (int tt = 0; tt < HCH; ++tt) {
-          const int c = lane + 64 * (hh * HCH + tt), row = c / CPR, cc = c - row * CPR;
+          const int c = lane + 64 * (hh * HCH + tt), row = min(c / CPR, grows - 1), cc = c - (c / CPR) * CPR;
           const int m = min(mw0 + ig * 32 + row, p.M - 1), n = nw0 + cc * EPC;
           xs[tt] = *(const f32x4*)((const float*)p.out + (int64_t)m * p.ldo + n);
           gs[tt] = *(const f32x4*)(p.gate + (int64_t)(m / p.ntok) * p.gate_bstride + n);
@@ -604,7 +800,8 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
         const int t = hh * HCH + tt;
         const int c = lane + 64 * t, row = c / CPR, cc = c - row * CPR;
         const int m = mw0 + ig * 32 + row, n = nw0 + cc * EPC;
-        const uint4 raw = *(const uint4*)(wbuf + row * RS + cc * 16);
+        const uint4 raw = *(const uint4*)(wbuf + (row < 32 ? row : 0) * RS + cc * 16);
+        if (row >= grows) continue;
         if (m < p.M) {
           if constexpr (EPI == EPI_RESID) {
             const int b = m / p.ntok;
@@ -638,7 +835,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
           for (int cc = 0; cc < HALF; ++cc) sq += *(const float*)(wbuf + r * RS + (h * HALF + cc) * 16);
           sq += __shfl_xor(sq, 1);
           const int m = mw0 + ig * 32 + r;
-          if (h == 0 && m < p.M) p.fold_part[(int64_t)m * p.fold_np + nw0 / (TN * 16)] = sq;
+          if (h == 0 && m < p.M && r < grows) p.fold_part[(int64_t)m * p.fold_np + nw0 / (TN * 16)] = sq;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -648,8 +845,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
 
   // ---- coalesced QKV epilogue: RoPE in registers, q/k through the LDS slab (16-B row-contiguous stores into
   // the q / k buffers), v tiles stored transposed directly (runs of 16 tokens per feature).
-  if constexpr (CE && EPI == EPI_QKV_ROPE) {
-    static_assert(TM % 2 == 0, "coalesced epilogue walks the wave tile 32 rows at a time");
+  if constexpr (CE && EPI == EPI_QKV_ROPE && TM % 2 == 0) {   // odd TM: direct epilogue below
     constexpr int RS = TN * 32 + 16, CPR = TN * 2, NCH = 32 * CPR / 64;
     static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
     __builtin_amdgcn_s_barrier();
@@ -759,7 +955,11 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nl = wn * TN * 16 + j * 16;      // tile-local first column of this MFMA tile (wave-uniform)
-        const f32x4 v = acc[i][j] * rstd_rows[i];
+        f32x4 v = acc[i][j] * rstd_rows[i];
+        if (p.bias) {   // folded norm: shift @ W^T of this step and layer, in the group-major column order of W
+          const float4 bq = *(const float4*)(p.bias + n0 + nl + fg * 4);
+          v[0] += bq.x; v[1] += bq.y; v[2] += bq.z; v[3] += bq.w;
+        }
         if (nl < 384) {
           const float r0 = __builtin_amdgcn_fractf((float)r * invf[j].x * 0.15915494309189535f);
           const float r1 = __builtin_amdgcn_fractf((float)r * invf[j].y * 0.15915494309189535f);
@@ -924,7 +1124,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64, (WM * WN
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int LDS = (PIPE >= 3 ? 3 : 2) * (BM + BN) * 128;
+  constexpr int LDS = ((PIPE >= 3 && PIPE != 8) ? 3 : 2) * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   static bool attr_set = false;
   auto kern = gemm_bf16_kernel<WM, WN, TM, TN, PIPE, CE, EPI>;
@@ -936,7 +1136,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (a.N % BN != 0 || a.K % 64 != 0 || a.M <= 0) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
   if (a.ksplit > 1 && EPI != EPI_F32) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit > 1 ? a.ksplit : 1), dim3((WM * WN + (PIPE >= 6 ? 4 : 0)) * 64), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit > 1 ? a.ksplit : 1), dim3((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0)) * 64), LDS, s, a);
   return hipGetLastError();
 }
 
@@ -966,16 +1166,18 @@ static const int kVariantTile[][2] = {
     {256, 160}, {256, 128},                          // 25-26: PIPE 6 (8 MFMA waves + 4 DMA waves)
     {64, 160}, {64, 128},                            // 27-28: small-M tiles (PIPE 2 + coalesced epilogue)
     {256, 160}, {256, 128},                          // 29-30: PIPE 7 (8 MFMA + 4 DMA waves, one barrier per K-tile)
+    {224, 320}, {256, 160}, {256, 256}, {128, 448},  // 31-34: PIPE 8 (quadrant ping-pong, 2 LDS stages) + coalesced epilogue
+    {224, 256},                                      // 35: PIPE 8
 };
 static const int kVariantWaveN[] = {64, 64, 64, 64, 80, 80, 64, 64, 80, 112, 32, 64, 80, 80, 80, 64, 80, 32,
-                                    80, 80, 64, 64, 80, 64, 80, 80, 64, 80, 64, 80, 64};
+                                    80, 80, 64, 64, 80, 64, 80, 80, 64, 80, 64, 80, 64, 80, 80, 64, 112, 64};
 int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
 bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
 
 hipError_t launch_qkv_attn(const GemmArgs& a, hipStream_t s) {
   if (a.ntok != 128 || a.N % 448 != 0 || a.M % 128 != 0) return hipErrorInvalidValue;
-  return launch_one<2, 4, 4, 7, 2, 0, EPI_QKV_ATTN>(a, s);
+  return launch_one<2, 4, 4, 7, 8, 0, EPI_QKV_ATTN>(a, s);
 }
 void gemm_variant_tile(int variant, int* bm, int* bn) {
   *bm = kVariantTile[variant][0];
@@ -986,6 +1188,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
   if (variant < 0 || variant >= gemm_num_variants()) return hipErrorInvalidValue;
   if (a.N % kVariantTile[variant][1] != 0) variant = (a.N % 128 == 0) ? 20 : 10;  // always-valid fallbacks
   switch (variant) {
+#ifndef JAT_DEV_VARIANTS   // dev builds (fast compile): only the variants the model picks + the new ones
     case 0: return launch_epi<2, 2, 4, 4, 0>(a, epi, s);
     case 1: return launch_epi<4, 2, 4, 4, 0>(a, epi, s);
     case 2: return launch_epi<2, 4, 8, 4, 0>(a, epi, s);
@@ -996,7 +1199,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 7: return launch_epi<2, 4, 8, 4, 1>(a, epi, s);
     case 8: return launch_epi<2, 2, 7, 5, 1>(a, epi, s);
     case 9: return launch_epi<2, 2, 7, 7, 1>(a, epi, s);
+#endif
     case 10: return launch_epi<2, 2, 4, 2, 1>(a, epi, s);
+#ifndef JAT_DEV_VARIANTS
     case 11: return launch_epi<2, 2, 4, 4, 2>(a, epi, s);
     case 12: return launch_epi<2, 2, 4, 5, 2>(a, epi, s);
     case 13: return launch_epi<4, 2, 4, 5, 2>(a, epi, s);
@@ -1004,19 +1209,31 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 15: return launch_epi<4, 2, 4, 4, 3>(a, epi, s);
     case 16: return launch_epi<4, 2, 4, 5, 3>(a, epi, s);
     case 17: return launch_epi<2, 4, 8, 2, 3>(a, epi, s);
+#endif
     case 18: return launch_epi<2, 2, 4, 5, 2, 1>(a, epi, s);
+#ifndef JAT_DEV_VARIANTS
     case 19: return launch_epi<4, 2, 4, 5, 2, 1>(a, epi, s);
+#endif
     case 20: return launch_epi<2, 2, 4, 4, 2, 1>(a, epi, s);
     case 21: return launch_epi<2, 4, 8, 4, 2, 1>(a, epi, s);
+#ifndef JAT_DEV_VARIANTS
     case 22: return launch_epi<4, 2, 4, 5, 4, 1>(a, epi, s);
     case 23: return launch_epi<4, 2, 4, 4, 4, 1>(a, epi, s);
     case 24: return launch_epi<4, 2, 4, 5, 5, 1>(a, epi, s);
+#endif
     case 25: return launch_epi<4, 2, 4, 5, 6, 1>(a, epi, s);
     case 26: return launch_epi<4, 2, 4, 4, 6, 1>(a, epi, s);
     case 27: return launch_epi<2, 2, 2, 5, 2, 1>(a, epi, s);
     case 28: return launch_epi<2, 2, 2, 4, 2, 1>(a, epi, s);
+#ifndef JAT_DEV_VARIANTS
     case 29: return launch_epi<4, 2, 4, 5, 7, 1>(a, epi, s);
     case 30: return launch_epi<4, 2, 4, 4, 7, 1>(a, epi, s);
+#endif
+    case 31: return launch_epi<2, 4, 7, 5, 8, 1>(a, epi, s);
+    case 32: return launch_epi<4, 2, 4, 5, 8, 1>(a, epi, s);
+    case 33: return launch_epi<2, 4, 8, 4, 8, 1>(a, epi, s);
+    case 34: return launch_epi<2, 4, 4, 7, 8, 1>(a, epi, s);
+    case 35: return launch_epi<2, 4, 7, 4, 8, 1>(a, epi, s);
   }
   return hipErrorInvalidValue;
 }

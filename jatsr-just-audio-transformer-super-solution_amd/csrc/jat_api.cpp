@@ -134,7 +134,8 @@ int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipSt
   const size_t o_pe_w1 = take((size_t)bott * m->Kp * 2), o_pe_w2 = take((size_t)D * bott * 2);
   const size_t o_wada = take((size_t)depth * 6 * D * D * 2), o_wfinal = take((size_t)m->Fout * D * 2);
   std::vector<size_t> o_qkv(depth), o_wo(depth), o_w1(depth), o_w2(depth), o_n1(depth), o_n2(depth), o_b1(depth),
-      o_b2(depth), o_qkvg(depth);
+      o_b2(depth), o_qkvg(depth), o_q32(depth), o_k32(depth), o_v32(depth), o_w132(depth);
+  const bool keep32 = rms;   // fold sources (RMSNorm models only)
   const bool group5 = m->Hq / m->Hkv == 5;
   for (int l = 0; l < depth; ++l) {
     o_qkv[l] = take((size_t)(D + 2 * kvD) * D * 2); o_wo[l] = take((size_t)D * D * 2);
@@ -142,7 +143,12 @@ int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipSt
     o_w1[l] = take((size_t)mlp * D * 2); o_w2[l] = take((size_t)D * mlp * 2);
     o_n1[l] = take((size_t)D * 4); o_n2[l] = take((size_t)D * 4);
     o_b1[l] = take((size_t)mlp * 4); o_b2[l] = take((size_t)D * 4);
+    if (keep32) {
+      o_q32[l] = take((size_t)D * D * 4); o_k32[l] = take((size_t)kvD * D * 4); o_v32[l] = take((size_t)kvD * D * 4);
+      o_w132[l] = take((size_t)mlp * D * 4);
+    }
   }
+  const size_t o_wfinal32 = keep32 ? take((size_t)m->Fout * D * 4) : 0;
   const size_t o_pe_b1 = take((size_t)bott * 4), o_pe_b2 = take((size_t)D * 4);
   const size_t o_te_w1 = take((size_t)D * D * 4), o_te_b1 = take((size_t)D * 4);
   const size_t o_te_w2 = take((size_t)D * D * 4), o_te_b2 = take((size_t)D * 4);
@@ -168,7 +174,14 @@ int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipSt
     L.w1 = (bf16_t*)(base + o_w1[l]); L.w2 = (bf16_t*)(base + o_w2[l]);
     L.norm1 = (float*)(base + o_n1[l]); L.norm2 = (float*)(base + o_n2[l]);
     L.b1 = (float*)(base + o_b1[l]); L.b2 = (float*)(base + o_b2[l]);
+    if (keep32) {
+      L.q32 = (float*)(base + o_q32[l]); L.k32 = (float*)(base + o_k32[l]); L.v32 = (float*)(base + o_v32[l]);
+      L.w132 = (float*)(base + o_w132[l]);
+    }
   }
+  m->wfinal32 = keep32 ? (float*)(base + o_wfinal32) : nullptr;
+  m->fold_cache.clear();   // folded tables belong to the previous weights (samplers that still hold one keep it alive)
+  m->fold_src_ok = false;
 
   // ---- copy / convert ----
   int rc = JAT_OK;
@@ -233,6 +246,12 @@ int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipSt
           rc = fail(JAT_E_HIP, "group-major qkv pack failed");
       }
     }
+    if (keep32 && build_tables) {   // fold sources: refreshed on a full load only (a training re-pack leaves them stale)
+      to_f32(p + "attn.q_proj.weight", L.q32, (int64_t)D * D);
+      to_f32(p + "attn.k_proj.weight", L.k32, (int64_t)kvD * D);
+      to_f32(p + "attn.v_proj.weight", L.v32, (int64_t)kvD * D);
+      to_f32(p + "mlp.0.weight", L.w132, (int64_t)mlp * D);
+    }
     to_bf16(p + "attn.out_proj.weight", L.wo, (int64_t)D * D);
     to_bf16(p + "mlp.0.weight", L.w1, (int64_t)mlp * D);
     to_f32(p + "mlp.0.bias", L.b1, mlp);
@@ -243,6 +262,7 @@ int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipSt
   }
   if (rms) to_f32("final_layer.0.weight", m->final_norm, D); else ones(m->final_norm, D);
   to_bf16("final_layer.1.weight", m->wfinal, (int64_t)m->Fout * D);
+  if (keep32 && build_tables) to_f32("final_layer.1.weight", m->wfinal32, (int64_t)m->Fout * D);
   to_f32("final_layer.1.bias", m->bfinal, m->Fout);
   if (rc != JAT_OK) return rc;
 
@@ -266,6 +286,7 @@ int jat_pack_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, hipSt
   }
   if (build_tables) HIPCHK(hipStreamSynchronize(s));
   m->group_copy_stale = false;
+  m->fold_src_ok = keep32 && build_tables;
   m->loaded = true;
   return JAT_OK;
 }
@@ -298,9 +319,12 @@ static int pick_variant(int M, int N, int nbatch = 1) {
   // at M = 7168 and M = 3584 (profiles/r01/gemm_variants_*.log).  Multi-round 1-block-per-CU variants pay 15 %:
   // their prologue/epilogue is not overlapped by a co-resident block.
   struct Cand { int id, bm, bn, slots; double f; };
+  // 31-35: quadrant ping-pong (PIPE 8), one 8-wave block per CU; calibrated on profiles/r02/gemm_variants_*.log
   static const Cand cands[] = {
       {20, 128, 128, 512, 0.80}, {18, 128, 160, 512, 0.95}, {25, 256, 160, 256, 1.00},
       {26, 256, 128, 256, 0.90}, {21, 256, 256, 256, 1.00}, {27, 64, 160, 512, 0.60},
+      {31, 224, 320, 256, 1.12}, {32, 256, 160, 256, 1.01}, {33, 256, 256, 256, 1.06},
+      {35, 224, 256, 256, 1.06},
   };
   int best = 20;
   double best_score = -1.0;
@@ -310,8 +334,10 @@ static int pick_variant(int M, int N, int nbatch = 1) {
     const long rounds = (t + c.slots - 1) / c.slots;
     double score = c.f * (double)t / (double)(rounds * c.slots);
     // multi-round penalty: the 12-wave DMA-wave variants (25, 26) pay their un-overlapped prologue/epilogue per round;
-    // the 8-wave 256x256 tile (21) does not (M = 9660, N = 5120: 110 us vs 124 us for 128x160, tools/gemm_shapes_bench.py)
-    if (c.slots == 256 && rounds > 1 && c.id != 21) score *= 0.85;
+    // the 8-wave tiles (21, 31-35) less so (M = 9660, N = 5120: 110 us vs 124 us for 128x160, tools/gemm_shapes_bench.py)
+    if (c.slots == 256 && rounds > 1 && (c.id == 25 || c.id == 26)) score *= 0.85;
+    // padding waste of a ragged last row tile counts against big tiles
+    score *= (double)M / (double)(((M + c.bm - 1) / c.bm) * c.bm);
     if (score > best_score) { best_score = score; best = c.id; }
   }
   return best;
@@ -329,9 +355,6 @@ int jat_gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const b
   if (N % kTileN(variant) != 0) variant = 20;  // 128 x 128, always valid
   if (a.fold_out) { a.fold_np = N / gemm_variant_wave_n(variant); m->last_fold_np = a.fold_np; }
   if (a.rs_part) a.rs_np = m->last_fold_np;
-  static const int fold_dbg = getenv("JAT_FOLD_NORM") ? atoi(getenv("JAT_FOLD_NORM")) : 0;  // 2/3: timing ablations
-  if (fold_dbg == 2) a.rs_part = nullptr;
-  if (fold_dbg == 3) a.fold_out = nullptr;
   static const int dbg_env = getenv("JAT_GEMM_DBG") ? atoi(getenv("JAT_GEMM_DBG")) : 0;  // profiling aid
   a.dbg = dbg_env;
   // measurement aid (bench.py roofline leg): bracket the launches of one call site with HIP events on the
@@ -364,12 +387,11 @@ static int adaln_path(const jat_model* m, const bf16_t* t_silu, float* mod, int 
   return gemm(m, G_OTHER, t_silu, m->D, m->wada + (int64_t)l0 * 6 * m->D * m->D, m->D, B, nl * 6 * m->D, m->D, EPI_F32, e, s);
 }
 
-// Norm folding (sampler path, RMSNorm only): per-step tables built once at jat_sampler_create.
-//   g     [depth][2][D]   w_norm * (1 + scale)   for norm1 / norm2 of every layer
-//   bq    [depth][D+2kvD] shift_msa @ Wqkv^T                    (added after the row rescale in the QKV epilogue)
-//   bf    [depth][mlp]    shift_mlp @ W1^T + b1
+// Norm folding (sampler path, RMSNorm only): this step's slice of the FoldTable (jat_internal.h); layer offsets are applied
+// in run_block.  wqkv_g != nullptr selects the fused QKV+attention kernel (group-major weights), else wqkv_i.
 struct Fold {
-  const float *g, *bq, *bf, *g_final;
+  const bf16_t *wqkv_g, *wqkv_i, *w1, *wfinal;
+  const float *bq_g, *bq_i, *bf;
 };
 
 // K-slices for a gated-residual GEMM [M, D] = A[M, K] W^T whose tiles do not fill the chip (small-M inference), 1 = none
@@ -393,21 +415,23 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   const char* fuse_s = getenv("JAT_FUSE_QKV_ATTN");  // read per call so that tests can A/B the two paths in one process
   const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
   // one block per (sample, KV group): worth it only when B * Hkv blocks fill the 256 CUs (measured: +1.8 % at
-  // B = 56, -5 % at B = 28); fuse_env = 2 forces it (tests)
-  const bool fused_attn = fuse_env && L.wqkv_g && !m->group_copy_stale && ntok == 128 && !f && (B * m->Hkv >= 192 || fuse_env == 2);
+  // B = 56, -5 % at B = 28); fuse_env = 2 forces it (tests).  With folded weights the sampler decided at creation.
+  const bool fused_attn = f ? f->wqkv_g != nullptr
+                            : (fuse_env && L.wqkv_g && !m->group_copy_stale && ntok == 128 && (B * m->Hkv >= 192 || fuse_env == 2));
   if (fused_attn) {
     // q/k/v projection + RoPE + attention of one (sample, KV group) per block: q, k, v stay in LDS
     GemmArgs a{};
-    a.A = w.xn; a.lda = D; a.W = L.wqkv_g; a.ldw = D; a.M = M; a.N = m->Hkv * 448; a.K = D;
+    a.A = w.xn; a.lda = D; a.W = f ? f->wqkv_g + (int64_t)l * Nqkv * D : L.wqkv_g; a.ldw = D; a.M = M; a.N = m->Hkv * 448; a.K = D;
     a.out = w.ao; a.ldo = D; a.ntok = ntok; a.rope_inv_freq = m->rope_invf;
     a.attn_scale_log2e = 0.125f * 1.4426950408889634f;
+    if (f) { a.rs_part = w.part; a.rs_np = m->last_fold_np; a.bias = f->bq_g + (int64_t)l * Nqkv; }
     KCHK(launch_qkv_attn(a, s));
   } else {
     GemmArgs e{};
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = ntok;
     e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin; e.rope_inv_freq = m->rope_invf;
-    if (f) { e.rs_part = w.part; e.bias = f->bq + (int64_t)l * Nqkv; }
-    JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, Nqkv, D, EPI_QKV_ROPE, e, s));
+    if (f) { e.rs_part = w.part; e.bias = f->bq_i + (int64_t)l * Nqkv; }
+    JCHK(gemm(m, G_QKV, w.xn, D, f ? f->wqkv_i + (int64_t)l * Nqkv * D : L.wqkv, D, M, Nqkv, D, EPI_QKV_ROPE, e, s));
   }
   if (!fused_attn) {
     AttnArgs a{};
@@ -419,7 +443,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
-    if (f) { e.fold_out = w.xn; e.fold_g = f->g + ((int64_t)l * 2 + 1) * D; e.fold_part = w.part; }
+    if (f) { e.fold_out = w.xn; e.fold_part = w.part; }
     const int split = resid_split(m, w, G_OUT, M, D, f != nullptr);
     if (split > 1) {
       GemmArgs p{};
@@ -435,15 +459,12 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     GemmArgs e{};
     e.out = w.hm; e.ldo = m->mlp; e.bias = L.b1; e.ntok = ntok;
     if (f) { e.rs_part = w.part; e.bias = f->bf + (int64_t)l * m->mlp; }
-    JCHK(gemm(m, G_FC1, w.xn, D, L.w1, D, M, m->mlp, D, EPI_BF16_GELU, e, s));
+    JCHK(gemm(m, G_FC1, w.xn, D, f ? f->w1 + (int64_t)l * m->mlp * D : L.w1, D, M, m->mlp, D, EPI_BF16_GELU, e, s));
   }
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = L.b2; e.gate = mod_l + 5 * D; e.gate_bstride = bstride; e.ntok = ntok;
-    if (f) {  // feeds the next layer's norm1, or the final norm
-      e.fold_out = w.xn; e.fold_part = w.part;
-      e.fold_g = (l + 1 < m->depth) ? f->g + ((int64_t)(l + 1) * 2) * D : f->g_final;
-    }
+    if (f) { e.fold_out = w.xn; e.fold_part = w.part; }   // feeds the next layer's norm1, or the final norm
     const int split = resid_split(m, w, G_FC2, M, m->mlp, f != nullptr);
     if (split > 1) {
       GemmArgs p{};
@@ -492,7 +513,7 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = m->pe_b2; e.ntok = ntok;
-    if (f) { e.fold_out = w.xn; e.fold_g = f->g; e.fold_part = w.part; }
+    if (f) { e.fold_out = w.xn; e.fold_part = w.part; }
     JCHK(gemm(m, G_OTHER, w.h_patch, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, e, s));
   }
   for (int l = 0; l < m->depth; ++l) JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s, f));
@@ -501,7 +522,7 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
     GemmArgs e{};
     e.out = x_pred; e.bias = m->bfinal; e.ntok = ntok; e.C_out = m->Cin; e.T_orig = T;
     if (f) e.rs_part = w.part;
-    JCHK(gemm(m, G_OTHER, w.xn, D, m->wfinal, D, M, m->Fout, D, EPI_UNPATCH, e, s));
+    JCHK(gemm(m, G_OTHER, w.xn, D, f ? f->wfinal : m->wfinal, D, M, m->Fout, D, EPI_UNPATCH, e, s));
   }
   return JAT_OK;
 }
@@ -593,7 +614,8 @@ struct jat_sampler {
   std::vector<float> ts;  // [host] linspace(0,1,steps+1)
   char* blob = nullptr;   // private device allocation
   float *z, *lr, *xpred, *mod_table, *ts_dev;
-  float *tab_g = nullptr, *tab_bq = nullptr, *tab_bf = nullptr;  // norm-folding tables (RMSNorm models)
+  std::shared_ptr<FoldTable> fold;   // per-step folded weights (RMSNorm models), shared through the model's cache
+  bool fused_attn = false;           // this bucket runs the fused QKV+attention kernel (group-major folded weights)
   float* pc = nullptr;   // CFG: patch(lr) @ W1[:, cond]^T, recomputed once per run (split patch embed)
   bool folded = false;
   void* ws;
@@ -632,14 +654,83 @@ static int sampler_steps(jat_sampler* sp, hipStream_t s) {
     const float t_curr = sp->ts[i], dt = sp->ts[i + 1] - sp->ts[i];
     Fold f{};
     if (sp->folded) {
-      f.g = sp->tab_g + (size_t)i * m->depth * 2 * m->D;
-      f.bq = sp->tab_bq + (size_t)i * m->depth * (m->D + 2 * m->kvD);
-      f.bf = sp->tab_bf + (size_t)i * m->depth * m->mlp;
-      f.g_final = m->final_norm;
+      const FoldTable& ft = *sp->fold;
+      const int64_t Nqkv = m->D + 2 * m->kvD, dl = m->depth;
+      if (sp->fused_attn) { f.wqkv_g = ft.qkv_g + (int64_t)i * dl * Nqkv * m->D; f.bq_g = ft.bq_g + (int64_t)i * dl * Nqkv; }
+      else { f.wqkv_i = ft.qkv_i + (int64_t)i * dl * Nqkv * m->D; f.bq_i = ft.bq_i + (int64_t)i * dl * Nqkv; }
+      f.w1 = ft.w1 + (int64_t)i * dl * m->mlp * m->D;
+      f.bf = ft.bf + (int64_t)i * dl * m->mlp;
+      f.wfinal = ft.wfinal;
     }
     JCHK(forward_impl(m, sp->w, sp->z, sp->B, sp->lr, sp->B, nullptr, sp->mod_table + i * row, 0, sp->xpred, sp->Bf,
                       sp->T, s, sp->folded ? &f : nullptr, sp->pc));
     KCHK(launch_cfg_euler(sp->xpred, sp->z, sp->cfg_scale, t_curr, dt, sp->use_cfg ? 1 : 0, n_half, s));
+  }
+  return JAT_OK;
+}
+
+// Build (or extend with the missing QKV layout) the folded-weight table of `steps` steps from the modulation table
+// mod [steps][depth*6D] (fp32, device).  Everything is enqueued on s; the caller synchronises.  On an allocation
+// failure the sampler simply runs un-folded (norm kernels).
+static int fold_alloc(FoldTable& ft, void** p, size_t bytes) {
+  if (hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); return fail(JAT_E_HIP, "hipMalloc(%zu) for the folded weights", bytes); }
+  ft.allocs.push_back(*p);
+  return JAT_OK;
+}
+static int build_fold_table(jat_model* m, FoldTable& ft, int steps, const float* mod, bool group_major, bf16_t* sh_bf16,
+                            hipStream_t s) {
+  const int D = m->D, kvD = m->kvD, mlp = m->mlp, depth = m->depth, Nqkv = D + 2 * kvD;
+  const int64_t mrow = (int64_t)depth * 6 * D;
+  const bool need_w1 = ft.w1 == nullptr;
+  const bool need_qkv = group_major ? ft.qkv_g == nullptr : ft.qkv_i == nullptr;
+  if (need_w1) {
+    JCHK(fold_alloc(ft, (void**)&ft.w1, (size_t)steps * depth * mlp * D * 2));
+    JCHK(fold_alloc(ft, (void**)&ft.bf, (size_t)steps * depth * mlp * 4));
+    JCHK(fold_alloc(ft, (void**)&ft.wfinal, (size_t)m->Fout * D * 2));
+    KCHK(launch_fold_weight(m->wfinal32, m->final_norm, nullptr, ft.wfinal, m->Fout, D, 0, s));
+  }
+  bf16_t* qkv = nullptr;
+  float* bq = nullptr;
+  if (need_qkv) {
+    JCHK(fold_alloc(ft, (void**)&qkv, (size_t)steps * depth * Nqkv * D * 2));
+    JCHK(fold_alloc(ft, (void**)&bq, (size_t)steps * depth * Nqkv * 4));
+    if (group_major) { ft.qkv_g = qkv; ft.bq_g = bq; } else { ft.qkv_i = qkv; ft.bq_i = bq; }
+  }
+  ft.steps = steps;
+  for (int l = 0; l < depth; ++l) {
+    const LayerW& L = m->layers[l];
+    for (int i = 0; i < steps; ++i) {
+      const float* mod_il = mod + i * mrow + (int64_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+      if (need_qkv) {
+        bf16_t* dst = qkv + ((int64_t)i * depth + l) * Nqkv * D;
+        if (group_major) {   // per KV head g: its 5 q heads, its k head, its v head (the layout of L.wqkv_g)
+          for (int g = 0; g < m->Hkv; ++g) {
+            bf16_t* dg = dst + (int64_t)g * 448 * D;
+            KCHK(launch_fold_weight(L.q32 + (int64_t)g * 320 * D, L.norm1, mod_il + D, dg, 320, D, 1, s));
+            KCHK(launch_fold_weight(L.k32 + (int64_t)g * 64 * D, L.norm1, mod_il + D, dg + (int64_t)320 * D, 64, D, 1, s));
+            KCHK(launch_fold_weight(L.v32 + (int64_t)g * 64 * D, L.norm1, mod_il + D, dg + (int64_t)384 * D, 64, D, 0, s));
+          }
+        } else {
+          KCHK(launch_fold_weight(L.q32, L.norm1, mod_il + D, dst, D, D, 1, s));
+          KCHK(launch_fold_weight(L.k32, L.norm1, mod_il + D, dst + (int64_t)D * D, kvD, D, 1, s));
+          KCHK(launch_fold_weight(L.v32, L.norm1, mod_il + D, dst + (int64_t)(D + kvD) * D, kvD, D, 0, s));
+        }
+      }
+      if (need_w1) KCHK(launch_fold_weight(L.w132, L.norm2, mod_il + 4 * D, ft.w1 + ((int64_t)i * depth + l) * mlp * D, mlp, D, 0, s));
+    }
+    // shift @ W^T for all steps of this layer in one skinny GEMM each (un-folded packed weights, fp32 accumulate)
+    if (need_qkv) {
+      KCHK(launch_gather_cast_rows(mod + (int64_t)l * 6 * D, mrow, sh_bf16, steps, D, s));
+      GemmArgs e{};
+      e.out = bq + (int64_t)l * Nqkv; e.ldo = (int64_t)depth * Nqkv; e.ntok = 1;
+      JCHK(gemm(m, G_OTHER, sh_bf16, D, group_major ? L.wqkv_g : L.wqkv, D, steps, Nqkv, D, EPI_F32, e, s));
+    }
+    if (need_w1) {
+      KCHK(launch_gather_cast_rows(mod + (int64_t)l * 6 * D + 3 * D, mrow, sh_bf16, steps, D, s));
+      GemmArgs e{};
+      e.out = ft.bf + (int64_t)l * mlp; e.ldo = (int64_t)depth * mlp; e.bias = L.b1; e.ntok = 1;
+      JCHK(gemm(m, G_OTHER, sh_bf16, D, L.w1, D, steps, mlp, D, EPI_F32, e, s));
+    }
   }
   return JAT_OK;
 }
@@ -660,6 +751,9 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   if (B <= 0 || T <= 0 || steps <= 0) return fail(JAT_E_INVALID, "B, T, steps must be positive");
   const int ntok = (T + 3) / 4;
   if (ntok > MAX_LEN) return fail(JAT_E_SEQLEN, "Sequence length %d exceeds max_len %d", ntok, MAX_LEN);
+  // The tables and the captured graph are built on a private stream: order them after everything already enqueued on
+  // the caller's streams (e.g. an asynchronous weight re-pack).  Creation is a slow path; a device sync is the simple order.
+  HIPCHK(hipDeviceSynchronize());
   jat_sampler* sp = new jat_sampler();
   sp->m = m; sp->B = B; sp->T = T; sp->steps = steps; sp->cfg_scale = cfg_scale;
   sp->use_cfg = cfg_scale != 1.0f;  // infer_test_v3m2.py:139
@@ -674,25 +768,27 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
   const size_t o_z = take(lat), o_lr = take(lat), o_xp = take((size_t)sp->Bf * m->Cin * T * 4);
   const size_t o_tab = take((size_t)steps * row * 4), o_ts = take((size_t)steps * 4), o_ws = take(ws_bytes);
-  const int Nqkv = m->D + 2 * m->kvD;
-  // Norm folding is implemented and parity-tested but measured NEUTRAL on MI355X (455 vs 452 ms per run: the two norm
-  // kernels it removes, 26 us per layer, are paid back by +8 us on each producer and consumer GEMM epilogue), so it
-  // is off by default; JAT_FOLD_NORM=1 enables it (DESIGN.md "what was tried").
-  const int fold_env = getenv("JAT_FOLD_NORM") ? atoi(getenv("JAT_FOLD_NORM")) : 0;  // read per sampler
-  {  // the consumer side reads the row partials lane-linear: needs 4, 8 or 16 slots per row
-    const int np = m->D / gemm_variant_wave_n(m->variants[G_OUT] >= 0 ? m->variants[G_OUT] : pick_variant(sp->Bf * ntok, m->D));
-    sp->folded = fold_env > 0 && m->cfg.norm_mode == JAT_NORM_RMS_W && (np == 4 || np == 8 || np == 16) &&
-                 m->variants[G_OUT] == m->variants[G_FC2] && m->variants[G_OUT] == m->variants[G_OTHER];
+  // Norm folding (default on for RMSNorm models; JAT_FOLD_NORM=0 keeps the norm kernels): decided per sampler.
+  const int fold_env = getenv("JAT_FOLD_NORM") ? atoi(getenv("JAT_FOLD_NORM")) : 1;
+  {  // the consumer side reads the row partials lane-linear: needs 4, 8 or 16 slots per row; the three producers of the
+     // residual stream (patch embed, out_proj, fc2: all [M, D]) must agree on the slot count
+    const int M = sp->Bf * ntok;
+    auto var = [&](int site) { return m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, m->D); };
+    const int np = m->D / gemm_variant_wave_n(var(G_OUT));
+    sp->folded = fold_env > 0 && m->cfg.norm_mode == JAT_NORM_RMS_W && m->fold_src_ok && (np == 4 || np == 8 || np == 16) &&
+                 gemm_variant_coalesced(var(G_OUT)) && var(G_OUT) == var(G_FC2) && var(G_OUT) == var(G_OTHER) &&
+                 (M > kSplitMaxRows || fold_env >= 2);   // small-M buckets finish fc2 / out_proj with split-K instead (2: force, tests)
+    const char* fuse_s = getenv("JAT_FUSE_QKV_ATTN");
+    const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
+    sp->fused_attn = fuse_env && m->Hq / m->Hkv == 5 && !m->group_copy_stale && ntok == 128 && (sp->Bf * m->Hkv >= 192 || fuse_env == 2);
   }
-  const size_t o_g = take((size_t)steps * m->depth * 2 * m->D * 4), o_bq = take((size_t)steps * m->depth * Nqkv * 4);
-  const size_t o_bf = take((size_t)steps * m->depth * m->mlp * 4), o_sh = take((size_t)steps * m->D * 2);
+  const size_t o_sh = take((size_t)steps * m->D * 2);
   const size_t o_pc = take((size_t)B * ntok * m->bott * 4);
   hipError_t e = hipMalloc((void**)&sp->blob, off);
   if (e != hipSuccess) { delete sp; return fail(JAT_E_HIP, "hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
   sp->z = (float*)(sp->blob + o_z); sp->lr = (float*)(sp->blob + o_lr); sp->xpred = (float*)(sp->blob + o_xp);
   sp->mod_table = (float*)(sp->blob + o_tab); sp->ts_dev = (float*)(sp->blob + o_ts);
   sp->ws = sp->blob + o_ws; sp->ws_bytes = ws_bytes;
-  sp->tab_g = (float*)(sp->blob + o_g); sp->tab_bq = (float*)(sp->blob + o_bq); sp->tab_bf = (float*)(sp->blob + o_bf);
   bf16_t* sh_bf16 = (bf16_t*)(sp->blob + o_sh);
   static const int split_env = getenv("JAT_SPLIT_PATCH") ? atoi(getenv("JAT_SPLIT_PATCH")) : 1;
   if (sp->use_cfg && split_env) sp->pc = (float*)(sp->blob + o_pc);
@@ -711,30 +807,15 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
     if ((rc = time_path(m, wt, sp->ts_dev, steps, s)) != JAT_OK) return bail(rc);
     if ((rc = adaln_path(m, wt.t_silu, sp->mod_table, steps, 0, m->depth, s)) != JAT_OK) return bail(rc);
     if (sp->folded) {
-      // fold tables: g = w_norm*(1+scale);  bq = shift_msa @ Wqkv^T;  bf = shift_mlp @ W1^T + b1   (per step, layer)
-      const int64_t mrow = (int64_t)m->depth * 6 * m->D;
-      for (int l = 0; l < m->depth; ++l) {
-        const LayerW& L = m->layers[l];
-        const float* mod_l = sp->mod_table + (int64_t)l * 6 * m->D;
-        if (launch_fold_scale(L.norm1, mod_l + 1 * m->D, mrow, sp->tab_g + ((int64_t)l * 2 + 0) * m->D,
-                              (int64_t)m->depth * 2 * m->D, steps, m->D, s) != hipSuccess ||
-            launch_fold_scale(L.norm2, mod_l + 4 * m->D, mrow, sp->tab_g + ((int64_t)l * 2 + 1) * m->D,
-                              (int64_t)m->depth * 2 * m->D, steps, m->D, s) != hipSuccess)
-          return bail(fail(JAT_E_HIP, "fold_scale launch"));
-        {
-          if (launch_gather_cast_rows(mod_l + 0 * m->D, mrow, sh_bf16, steps, m->D, s) != hipSuccess)
-            return bail(fail(JAT_E_HIP, "gather_cast launch"));
-          GemmArgs e{};
-          e.out = sp->tab_bq + (int64_t)l * Nqkv; e.ldo = (int64_t)m->depth * Nqkv; e.ntok = 1;
-          if ((rc = gemm(m, G_OTHER, sh_bf16, m->D, L.wqkv, m->D, steps, Nqkv, m->D, EPI_F32, e, s)) != JAT_OK) return bail(rc);
-        }
-        {
-          if (launch_gather_cast_rows(mod_l + 3 * m->D, mrow, sh_bf16, steps, m->D, s) != hipSuccess)
-            return bail(fail(JAT_E_HIP, "gather_cast launch"));
-          GemmArgs e{};
-          e.out = sp->tab_bf + (int64_t)l * m->mlp; e.ldo = (int64_t)m->depth * m->mlp; e.bias = L.b1; e.ntok = 1;
-          if ((rc = gemm(m, G_OTHER, sh_bf16, m->D, L.w1, m->D, steps, m->mlp, m->D, EPI_F32, e, s)) != JAT_OK) return bail(rc);
-        }
+      // per-step folded weights: shared by every sampler of this model with the same step count (model-level cache)
+      std::shared_ptr<FoldTable>& slot = m->fold_cache[steps];
+      if (!slot) slot = std::make_shared<FoldTable>();
+      if (build_fold_table(m, *slot, steps, sp->mod_table, sp->fused_attn, sh_bf16, s) != JAT_OK) {
+        (void)hipStreamSynchronize(s);
+        m->fold_cache.erase(steps);   // e.g. out of memory: run this sampler with the norm kernels
+        sp->folded = false;
+      } else {
+        sp->fold = slot;
       }
     }
     if (hipStreamSynchronize(s) != hipSuccess) return bail(fail(JAT_E_HIP, "sync after table build"));

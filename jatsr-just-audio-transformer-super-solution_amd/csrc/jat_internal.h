@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -36,6 +38,20 @@ struct LayerW {
   bf16_t *wqkv, *wo, *w1, *w2;  // [D+2kvD, D], [D, D], [mlp, D], [D, mlp]
   bf16_t* wqkv_g = nullptr;     // group-major copy [Hkv][5*64 + 64 + 64][D] for the fused QKV+attention kernel (Hq/Hkv == 5)
   float *norm1, *norm2, *b1, *b2;
+  float *q32 = nullptr, *k32 = nullptr, *v32 = nullptr, *w132 = nullptr;   // fp32 copies: sources of the sampler's folded weights
+};
+
+// Per-step folded weights of the sampler (RMSNorm models): W' = W diag(w_norm (1 + scale)) and shift @ W^T for every
+// (step, layer) of a fixed schedule — input independent, built once per (model weights, steps) and shared by every sampler
+// bucket (B, T) with that step count.  ~25 GB for v3mod2 at 50 steps: HBM capacity (288 GB) spent to delete the two norm
+// kernels of every block from the captured graph.
+struct FoldTable {
+  int steps = 0;
+  bf16_t *qkv_g = nullptr, *qkv_i = nullptr;   // [steps][depth][D+2kvD][D]: group-major (fused QKV+attention) / pair-interleaved
+  bf16_t *w1 = nullptr, *wfinal = nullptr;     // [steps][depth][mlp][D], [Fout][D]
+  float *bq_g = nullptr, *bq_i = nullptr, *bf = nullptr;   // [steps][depth][D+2kvD] x2, [steps][depth][mlp]
+  std::vector<void*> allocs;
+  ~FoldTable() { for (void* p : allocs) (void)hipFree(p); }
 };
 
 struct jat_model {
@@ -50,6 +66,9 @@ struct jat_model {
   // GEMM tile/pipeline variant per call site: qkv, out_proj, fc1, fc2, everything else (gemm.hip table)
   int variants[5] = {-1, -1, -1, -1, -1};  // -1: choose by shape (pick_variant)
   mutable int last_fold_np = 0;            // partial-sum slots per row written by the latest folding producer
+  float* wfinal32 = nullptr;               // fp32 copy of final_layer.1.weight (fold source)
+  bool fold_src_ok = false;                // fp32 copies match the packed weights (false after a training re-pack)
+  std::map<int, std::shared_ptr<FoldTable>> fold_cache;   // by step count; dropped whenever the weights change
   bool group_copy_stale = false;           // the training re-pack skips wqkv_g: the fused QKV+attention kernel is off until
                                            // the next full jat_model_load_weights
 };

@@ -41,13 +41,13 @@ struct GemmArgs {
   int C_out, T_orig;
   int dbg;  // profiling aid (bit0: suppress epilogue stores); 0 in production
   // ---- norm folding (sampler path; coalesced-epilogue variants only) ------------------------------------------
-  // RMSNorm commutes with the matmul: norm(x)*g + sh  @ W^T  =  rstd[m] * ((x*g) @ W^T) + (sh @ W^T).
-  // producer (EPI_RESID / EPI_F32): besides x, emit A'[m][n] = bf16(x_new * fold_g[b][n]) and the row partial
-  //   sums of x_new^2 of this wave's column tile into fold_part[m][nw0 / wave_tile_n]  (plain stores, fixed order);
+  // RMSNorm commutes with the matmul, and in the sampler every row shares the modulation (one t per step), so
+  //   (x * rstd * w * (1 + scale) + shift) @ W^T  =  rstd[m] * (bf16(x) @ W'^T) + (shift @ W^T),   W' = W diag(w (1 + scale))
+  // with W' and shift @ W^T precomputed per (step, layer) at sampler creation (jat_api.cpp FoldTable).
+  // producer (EPI_RESID / EPI_F32): besides x, emit fold_out[m][n] = bf16(x_new) and the row partial sums of x_new^2
+  //   of this wave's column tile into fold_part[m][nw0 / wave_tile_n]  (plain stores, fixed order);
   // consumer (any epilogue): scale the accumulator row m by rsqrt(sum_j rs_part[m][j] / K + 1e-6) before the bias.
   bf16_t* fold_out;
-  const float* fold_g;
-  int64_t fold_g_bstride;
   float* fold_part;
   int fold_np;
   const float* rs_part;
@@ -112,6 +112,10 @@ hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t
 // fp32 [rows, cols] -> bf16 with the rows of every 64-row head pair-interleaved for in-lane RoPE:
 // out row (h*64 + 2d + e) <- in row (h*64 + d + 32e), e in {0,1}   (rows % 64 == 0)
 hipError_t launch_cast_bf16_rope_rows(const float* in, bf16_t* out, int rows, int cols, hipStream_t s);
+// weight folding (sampler): out[r][c] = bf16(in[src(r)][c] * w[c] * (1 + scale[c]))  (scale may be null; rope: rows
+// pair-interleaved per 64-row head like launch_cast_bf16_rope_rows)
+hipError_t launch_fold_weight(const float* in, const float* w, const float* scale, bf16_t* out, int rows, int cols, int rope,
+                              hipStream_t s);
 // norm-folding table helpers: out[r][k] = w[k] * (1 + scale[r*in_stride + k]) ; out[r][k] = bf16(in[r*in_stride + k])
 hipError_t launch_fold_scale(const float* w, const float* scale, int64_t in_stride, float* out, int64_t out_stride,
                              int rows, int cols, hipStream_t s);

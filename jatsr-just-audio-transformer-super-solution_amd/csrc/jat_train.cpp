@@ -93,6 +93,8 @@ int repack(jat_trainer* tr, hipStream_t s) {
   const float* P = tr->P;
   const int D = m->D, kvD = m->kvD, mlp = m->mlp;
   m->group_copy_stale = true;
+  m->fold_src_ok = false;    // the sampler's folded-weight tables (jat_api.cpp FoldTable) describe the previous weights:
+  m->fold_cache.clear();     // samplers created from now on run the norm kernels until the next full load
   KCHK(launch_multi_copy(tr->copy_jobs, tr->n_copy_jobs, s));
   KCHK(launch_cast_bf16(P + tr->o_pe_w1, m->pe_w1, (int64_t)m->bott * m->Kp, s));
   KCHK(launch_cast_bf16(P + tr->o_pe_w2, m->pe_w2, (int64_t)D * m->bott, s));

@@ -178,6 +178,9 @@ def main(which):
     if allc or "v3mod2" in which:
         forward_case("v3mod2_T512", "v3mod2", 2, 512, [0.02, 0.98])
         forward_case("v3mod2_T1378", "v3mod2", 1, 1378, [0.5], salt=1, s_out=(37, 13))
+        # the benchmarked sampler shape (T = 512, CFG = 3.0) at full model size, 4 Euler steps (a 50-step run is ~20 min of
+        # CPU per sample); the GPU test also runs these two samples as rows 0-1 of a B = 28 batch through the hipGraph
+        sampler_case("v3mod2_cfg3_4step", "v3mod2", 2, 512, 4, 3.0)
     if allc or "misc" in which:
         misc_case()
 

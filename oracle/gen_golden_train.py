@@ -126,6 +126,43 @@ def train_case(name, cfg_name, B, T, t_list, mask_list, norm="rms", salt=0, lr_r
           f"loss32-loss64={rec['loss32'] - rec['loss64']:.2e} ({sz / 1024:.0f} KiB)")
 
 
+def big_case(name, cfg_name, B, T, t_list, mask_list, norm="rms", salt=0, clip=1.0, strides=(211, 97)):
+    """Full-size (v3mod2: 766 M parameters, depth 28) step: loss, every parameter gradient (sub-sampled + full L2
+    norms) and the clip norm of the reference model under fp64 autograd.  One precision and no optimiser state, so that
+    the run fits the build container (model 6 GB + gradients 6 GB); the AdamW arithmetic is pinned by the small cases."""
+    cfg = recipe.CONFIGS[cfg_name]
+    hr, lr, noise = step_inputs(cfg, B, T, salt)
+    t = np.asarray(t_list, dtype=np.float32)
+    mask = np.asarray(mask_list, dtype=bool)
+    dt = torch.float64
+    m = ref_model(cfg, norm, salt, dt)
+    hr_t, lr_t, nz = (torch.from_numpy(a).to(dt) for a in (hr, lr, noise))
+    tt = torch.from_numpy(t).to(dt)
+    lr_in = lr_t * (~torch.from_numpy(mask).view(B, 1, 1)).to(dt)
+    tv = tt.view(-1, 1, 1)
+    pred = m(tv * hr_t + (1 - tv) * nz, tt, lr_in)
+    loss = torch.nn.functional.mse_loss(pred, hr_t)
+    loss.backward()
+    rec = {"loss64": np.float64(loss.item()), "pred_l2": np.float64(pred.detach().norm().item())}
+    sq = 0.0
+    names = []
+    for k, p_ in m.named_parameters():
+        names.append(k)
+        g = p_.grad
+        rec["g_" + k] = sub(g.numpy(), strides)
+        n = float(g.norm().item())
+        rec["gl2_" + k] = np.float64(n)
+        sq += n * n
+        p_.grad = None
+    rec["gnorm64"] = np.float64(sq ** 0.5)     # what clip_grad_norm_ returns (train_ddp_v3m2.py:615)
+    rec["meta"] = json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, t=[float(v) for v in t],
+                                  mask=[bool(v) for v in mask], norm=norm, salt=salt, lr=5e-5, wd=0.1, clip=clip,
+                                  full_limit=FULL_LIMIT, strides=strides, torch=torch.__version__, names=names))
+    np.savez_compressed(os.path.join(GOLD, f"train_{name}.npz"), **rec)
+    sz = os.path.getsize(os.path.join(GOLD, f"train_{name}.npz"))
+    print(f"[golden] train_{name}: loss={rec['loss64']:.6f} gnorm={rec['gnorm64']:.4f} ({sz / 1024:.0f} KiB)")
+
+
 def dropout_case(name, cfg_name, B, T, t_list, seed, dropout=0.1, drop_path_rate=0.05, salt=0, strides=(7, 5)):
     """Train-mode Dropout / DropPath of the REFERENCE with injected masks.  torch's Philox stream cannot be reproduced
     on another device, so the masks come from the counter-based generator of csrc/jat_rng.h (numpy mirror
@@ -299,6 +336,13 @@ def main(which):
         loss_case("T1378", 1, 64, 1378, salt=3)           # the trainer's crop: 690 bins, bands at 207 / 248
         mod2_step_case("micro_mod2_T24", "micro", 2, 24, [0.1, 0.85], salt=2)
         mod2_step_case("tiny_mod2_T128", "tiny", 2, 128, [0.2, 0.9], salt=1, strides=(61, 53))
+        # well-conditioned variant (no log-magnitude term): the end-to-end v3mod2 gradient can be compared with the
+        # reference's autograd directly (with fw > 0, d loss / d pred is sign(.)/(|P_k| + 1e-7): ill-conditioned)
+        mod2_step_case("micro_mod2fw0_T24", "micro", 2, 24, [0.1, 0.85], salt=2, fw=0.0)
+        mod2_step_case("tiny_mod2fw0_T128", "tiny", 2, 128, [0.2, 0.9], salt=1, strides=(61, 53), fw=0.0)
+    if "v3mod2" in which:   # full-size model: ~15 GB of host memory, a few minutes; not part of the default set
+        big_case("v3mod2_T128", "v3mod2", 2, 128, [0.2, 0.9], [False, True])
+        big_case("v3mod2_T70_ragged", "v3mod2", 2, 70, [0.35, 0.8], [False, False], salt=1)
     if allc or "misc" in which:
         u_shape_case()
 

@@ -5,6 +5,7 @@ operands (fp64 accumulate), so the only admissible differences are fp32 accumula
 bf16 rounding: tolerances are stated per test.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -81,10 +82,17 @@ def test_norm_no_modulation():
 
 
 GEMM_SHAPES = [(128, 128, 64), (256, 512, 128), (1000, 1792, 1280), (56, 1536, 256), (1035, 1280, 5120),
-               (384, 256, 8192)]
+               (384, 256, 8192),
+               # N divisible by 160 / 320 / 448 (the wide tiles), K-tile counts 1, 2, 3 (pipeline prologue / tail paths)
+               (300, 2240, 64), (300, 2240, 128), (500, 4480, 192)]
 
 
-@pytest.mark.parametrize("variant", list(range(31)))
+# every tile / pipeline variant of gemm.hip; JAT_TEST_VARIANTS="31,32" narrows the sweep (dev builds of the library
+# compile a subset: csrc/Makefile `dev`)
+GEMM_VARIANTS = [int(v) for v in os.environ.get("JAT_TEST_VARIANTS", "").split(",") if v] or list(range(35))
+
+
+@pytest.mark.parametrize("variant", GEMM_VARIANTS)
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm(variant, M, N, K, epi):

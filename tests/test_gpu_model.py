@@ -216,9 +216,10 @@ def test_sampler_vs_reference_golden(name):
 
 
 def test_sampler_with_norm_folding_matches_golden(monkeypatch):
-    """JAT_FOLD_NORM=1: RMSNorm folded into the GEMM epilogues (rstd applied after the matmul, shift @ W^T tables
-    per step) — an alternative sampler path that must meet the same parity gate and stay deterministic."""
-    monkeypatch.setenv("JAT_FOLD_NORM", "1")
+    """Norm folding (the sampler's default at large M): RMSNorm weight and adaLN scale folded into per-step copies of the
+    consumer weights, rstd applied after the matmul, shift @ W^T tables per step — no norm kernel in the captured graph.
+    Must meet the same parity gate as the un-folded path and stay deterministic."""
+    monkeypatch.setenv("JAT_FOLD_NORM", "2")    # 2 = also at small M (by default only buckets of > 2304 rows fold)
     z, meta = load_golden("sampler_tiny_cfg3")
     cfg, lr, z0 = sampler_inputs(meta)
     m = JaT_AudioSR_V3(**cfg)                      # fresh module: fresh handle and sampler cache
@@ -230,6 +231,69 @@ def test_sampler_with_norm_folding_matches_golden(monkeypatch):
                                        z0=cuda(z0), use_graph=False)
     assert torch.equal(a, b)
     assert rel_l2(sub(a.cpu().numpy(), *meta["s_out"]), z["z"]) < SAMPLER_TOL
+
+
+def test_sampler_at_benchmarked_shape_vs_reference_golden():
+    """BASELINE configs[2] dims: v3mod2 (D = 1280, depth 28, 20Q/4KV), T = 512, CFG = 3.0, against the reference's own
+    `flow_matching_sample` (4 Euler steps, fixture generated by oracle/gen_golden.py on the reference classes).
+      (a) the B = 2 bucket;
+      (b) the B = 28 bucket bench.py times — rows 0-1 are the same two samples, rows 2-27 other data.  At M = 7168 the path
+          differs from every small test: fused QKV+RoPE+attention kernel, 224 x 320 / 256 x 160 quadrant-ping-pong tiles,
+          split patch embed, per-step folded weights (no norm kernels), one hipGraph.  Rows 0-1 must meet the same gate
+          against the reference, agree with the B = 2 bucket to rounding, the graph must equal the eager replay bit for bit,
+          and shuffling the OTHER rows must not change rows 0-1 by a single bit (batch-row independence)."""
+    z, meta = load_golden("sampler_v3mod2_cfg3_4step")
+    cfg, lr, z0 = sampler_inputs(meta)
+    m = build(meta["cfg"], "rms", meta["salt"])
+    kw = dict(num_steps=meta["steps"], cfg_scale=meta["cfg_scale"], verbose=False)
+    out2 = jatsr_amd.flow_matching_sample(m, cuda(lr), z0=cuda(z0), **kw).cpu().numpy()
+    r2 = rel_l2(sub(out2, *meta["s_out"]), z["z"])
+    C, T = lr.shape[1], lr.shape[2]
+    lr28 = np.concatenate([lr, recipe.gaussian("lr_fill", (26, C, T), 7)], 0)
+    z28 = np.concatenate([z0, recipe.gaussian("z0_fill", (26, C, T), 8)], 0)
+    g28 = jatsr_amd.flow_matching_sample(m, cuda(lr28), z0=cuda(z28), **kw)
+    e28 = jatsr_amd.flow_matching_sample(m, cuda(lr28), z0=cuda(z28), use_graph=False, **kw)
+    assert torch.equal(g28, e28)
+    o28 = g28.cpu().numpy()
+    assert np.isfinite(o28).all()
+    r28 = rel_l2(sub(o28[:2], *meta["s_out"]), z["z"])
+    rb = rel_l2(o28[:2], out2)
+    print(f"sampler v3mod2 4-step CFG=3: B=2 bucket rel-L2 {r2:.3e}, B=28 bucket rows 0-1 rel-L2 {r28:.3e}, "
+          f"B=28 vs B=2 {rb:.3e}")
+    assert r2 < SAMPLER_TOL and r28 < SAMPLER_TOL and rb < 1e-2
+    assert abs(np.linalg.norm(o28[:2].astype(np.float64)) / float(z["z_l2"]) - 1) < 1e-2
+    perm = np.concatenate([[0, 1], np.arange(27, 1, -1)])
+    p28 = jatsr_amd.flow_matching_sample(m, cuda(lr28[perm]), z0=cuda(z28[perm]), **kw)
+    assert torch.equal(p28[:2], g28[:2])
+
+
+def test_sample_long_at_v3mod2_dims_batched_equals_chunk_by_chunk():
+    """BASELINE configs[4] dims: one file of T = 4096 latent frames, v3mod2 model, reference chunk plan (3 x 1378 + 478
+    frames, overlap 172; infer_test_v3m2.py:340-404).  `sample_long` batches the equal-length chunks into one sampler
+    launch; the reference samples them one at a time (B = 1, :370-398).  Same inputs, same noise: the two must agree to
+    rounding (different GEMM tile choices at M = 2070 vs 690 rows), and the file's crossfade must equal the oracle's."""
+    m = build("v3mod2")
+    Cc, total = 1024, 4096
+    lr = cuda(recipe.gaussian("long_lr", (Cc, total), 1) * 1.5 + 0.2)
+    mean = cuda(recipe.gaussian("mean", (Cc,), 2) * 0.1)
+    std = cuda(np.abs(recipe.gaussian("std", (Cc,), 3)) + 0.5)
+    plan = jatsr_amd.chunk_plan(total)
+    assert [b - a for a, b in plan] == [1378, 1378, 1378, 478] and plan == O.chunk_plan(total)
+    noise = [cuda(recipe.gaussian("noise", (1, Cc, b - a), i)) for i, (a, b) in enumerate(plan)]
+    got = jatsr_amd.sample_long(m, lr, mean, std, mean, std, num_steps=3, cfg_scale=3.0, noise=noise)
+    outs = []
+    for i, (a, b) in enumerate(plan):
+        c = (lr[None, :, a:b] - mean.view(1, -1, 1)) / std.view(1, -1, 1)
+        g = jatsr_amd.flow_matching_sample(m, c, num_steps=3, cfg_scale=3.0, verbose=False, z0=noise[i])
+        outs.append((g * std.view(1, -1, 1) + mean.view(1, -1, 1)).cpu().numpy())
+    ref = O.crossfade_chunks(outs, 172)
+    g = got.cpu().numpy()
+    assert g.shape == (1, Cc, total) and np.isfinite(g).all()
+    r = rel_l2(g, ref)
+    print(f"sample_long v3mod2 T=4096: batched vs chunk-by-chunk rel-L2 {r:.3e}")
+    assert r < 1e-2
+    # the short last chunk is its own bucket in both runs: its un-faded tail is bit-identical
+    assert np.array_equal(g[:, :, 3618 + 172:], outs[3][:, :, 172:])
 
 
 def test_graph_replay_is_deterministic():

@@ -68,6 +68,47 @@ CASES = ["train_micro_T24", "train_micro_T22_pad", "train_micro_ln_T24", "train_
 
 @pytest.mark.parametrize("name", CASES)
 def test_train_step_vs_reference_golden(name):
+    _check_step_vs_golden(name, with_adamw=True)
+
+
+BIG_CASES = ["train_v3mod2_T128", "train_v3mod2_T70_ragged"]
+
+
+@pytest.mark.parametrize("name", BIG_CASES)
+def test_v3mod2_depth28_step_vs_reference_golden(name):
+    """The full-size model (D = 1280, depth 28, 20Q/4KV, 766 M parameters; BASELINE configs[3] dims) against the reference's
+    fp64 autograd (oracle/gen_golden_train.py `big_case`): loss, clip norm and all 345 parameter gradients (sub-sampled
+    values + full L2 norms), at N = 32 tokens and at a ragged T = 70 (padded to 72, N = 18)."""
+    _check_step_vs_golden(name, with_adamw=False)
+
+
+def test_v3mod2_B28_step_is_deterministic_and_finite():
+    """configs[3] shape on one GPU: B = 28 per rank, T = 512, depth 28.  Two forward+backward passes from the same state
+    give bit-identical gradients (every reduction is partials + fixed-order finish), the loss and the clip norm are finite,
+    and one AdamW step changes the prediction."""
+    z, meta = load_golden("train_v3mod2_T128")
+    meta = dict(meta, B=28, T=512, t=[0.02 + 0.035 * i for i in range(28)], mask=[i % 9 == 0 for i in range(28)])
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    tr.forward_backward(z_t, t2, cond, hr)
+    g1 = tr.grads.clone()
+    loss1 = float(tr._scal[0])
+    pred = tr.forward_backward(z_t, t2, cond, hr, want_pred=True)
+    assert torch.equal(tr.grads, g1) and float(tr._scal[0]) == loss1
+    assert math.isfinite(loss1) and bool(torch.isfinite(g1).all()) and bool(torch.isfinite(pred).all())
+    # rows of the batch are independent in the forward: sample 3 alone predicts what it predicts inside the batch
+    # (different tile shapes at M = 128 vs 3584: bf16 rounding points differ, the math does not)
+    m.eval()
+    alone = m(z_t[3:4], t2[3:4], cond[3:4])
+    assert rel_l2(alone.cpu().numpy(), pred[3:4].float().cpu().numpy()) < 2e-2
+    loss2, gnorm = tr.optimizer_step(lr=meta["lr"])
+    assert math.isfinite(gnorm) and gnorm > 0 and abs(loss2 - loss1) < 1e-6
+    after = m(z_t[3:4], t2[3:4], cond[3:4])
+    assert bool(torch.isfinite(after).all()) and not torch.equal(after, alone)
+
+
+def _check_step_vs_golden(name, with_adamw):
     z, meta = load_golden(name)
     m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
     assert [k for k, _ in m.named_parameters()] == meta["names"]   # same tensors, same order as the reference
@@ -100,6 +141,8 @@ def test_train_step_vs_reference_golden(name):
     print(f"{name}: loss {loss:.6f} (ref {float(z['loss64']):.6f}) gnorm {gnorm:.5f} (ref {gn_ref:.5f}) "
           f"worst tensor {worst[0]} at {worst[1]:.2f} of its tolerance")
     assert abs(gnorm - gn_ref) <= GNORM_TOL * gn_ref
+    if not with_adamw:
+        return
     # ---- clip + AdamW: parameter deltas of the first step (|delta| ~ lr for every element: sign-dominated) ----------
     before = {k: p.detach().clone() for k, p in m.named_parameters()}
     loss2, gnorm2 = tr.optimizer_step(lr=meta["lr"])
@@ -330,6 +373,45 @@ def test_v3mod2_step_vs_reference_golden(name):
     mean, std = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     st = tr.train_step(hr, lr, mean, std, mean, std)
     assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]) and tr.loss_terms()["latent"] > 0
+
+
+@pytest.mark.parametrize("name", ["train_micro_mod2fw0_T24", "train_tiny_mod2fw0_T128"])
+def test_v3mod2_step_gradients_vs_reference_autograd_conditioned(name):
+    """End-to-end v3mod2 gradients against the REFERENCE's own autograd (the `g_*` values gen_golden_train.py stored),
+    on a well-conditioned variant of the loss: freq_weight = 0 removes the log-magnitude term whose d/d pred is
+    sign(.)/(|P_k| + 1e-7).  What remains (MSE + multi-scale L1 + band consistency against the clean LR latent) is
+    piecewise smooth, so the whole chain  loss kernel -> d pred -> 28-kernel backward  is pinned to reference autograd
+    directly, not through the numpy oracle.  The L1 terms' sign(.) still flips for the few elements the bf16 forward
+    moves across zero: the gate is the per-tensor tolerance of the MSE-only cases, doubled."""
+    z, meta = load_golden(name)
+    assert meta["fw"] == 0.0
+    m, tr = make_trainer(dict(meta, lr=5e-5, wd=0.1, clip=1.0), use_grad_scaler=False, condition_noise_ratio=0.0,
+                         latent_loss_weight=meta["lw"], freq_loss_weight=meta["fw"], ms_loss_weight=meta["mw"],
+                         consistency_weight=meta["cw"])
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    C, B, T, salt = cfg["input_channels"], meta["B"], meta["T"], meta["salt"]
+    hr = cuda(recipe.gaussian("train_hr", (B, C, T), salt + 300))
+    lr = cuda(recipe.gaussian("train_lr", (B, C, T), salt + 301))
+    noise = cuda(recipe.gaussian("train_noise", (B, C, T), salt + 302))
+    cn = cuda((0.05 * recipe.gaussian("train_cnoise", (B, C, T), salt + 303)).astype(np.float32))
+    t = cuda(np.asarray(meta["t"], np.float32))
+    z_t, t2, _ = tr.prepare(hr, lr, noise=noise, cfg_mask=torch.zeros(B, dtype=torch.bool), t=t)
+    tr.forward_backward(z_t, t2, lr + cn, hr, cond_clean=lr)
+    terms = tr.loss_terms()
+    assert abs(terms["total"] - float(z["loss64"])) <= LOSS_TOL * float(z["loss64"]), (terms, float(z["loss64"]))
+    gn_ref = math.sqrt(sum(float(z["gl2_" + k]) ** 2 for k in meta["names"]))
+    worst, sq = ("", 0.0), 0.0
+    for k in meta["names"]:
+        g = tr.grad(k).detach().cpu().numpy()
+        sq += float((g.astype(np.float64) ** 2).sum())
+        ref_l2 = float(z["gl2_" + k])
+        r = rel_l2(gsub(g, meta), z["g_" + k])
+        tol = 2 * (GRAD_TOL if ref_l2 >= 1e-3 * gn_ref else GRAD_TOL_SMALL)
+        if r / tol > worst[1]:
+            worst = (k, r / tol)
+        assert r <= tol, f"{k}: grad rel-L2 {r:.3e} vs reference autograd (ref norm {ref_l2:.3e})"
+    print(f"{name}: {terms}; gnorm {sq ** 0.5:.5f} (ref {gn_ref:.5f}); worst tensor {worst[0]} at {worst[1]:.2f} of tolerance")
+    assert abs(sq ** 0.5 - gn_ref) <= 2 * GNORM_TOL * gn_ref
 
 
 def test_validate_and_checkpoint_roundtrip(tmp_path):
