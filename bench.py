@@ -15,8 +15,14 @@ Extra objects on the same JSON line:
   forward      — single DiT forward (configs[1]) frames/s and its fraction of the bf16 MFMA peak.
 
     python bench.py                                    # 1 GPU, defaults
+    python bench.py --gpus 8 [--scaling strong]        # starts 8 ranks itself (torch.distributed.run child, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W          # the driver's own launch: used as is
+
+--scaling weak (default): every rank samples its own B=28 batch.  --scaling strong: ONE B=28 batch is sharded over the
+ranks with jatsr_amd.dist.shard_range (28 -> 14,14 -> 7,7,7,7 -> 4,4,4,4,3,3,3,3), value = 28*T*steps / max-over-ranks time.
+--dry-run: CPU-only rehearsal of the launcher / rendezvous / timing contract (gloo, a stand-in numpy step) — what the
+world_size-2 CPU test runs; never a measurement.
 """
 import argparse
 import ctypes as C
@@ -31,6 +37,78 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+# SURVEY.md §6 / BASELINE.md §2: the REFERENCE's own fp32 torch-CPU forward, measured in the survey container (8 vCPU Xeon
+# 2.1 GHz, torch 2.10 CPU, 8 threads).  Carried beside the port's number so that the CPU baseline never flatters the ratio.
+REFERENCE_TORCH_CPU_SURVEY = {"forward_latent_frames_per_s": [1408.0, 1548.0], "cores": 8,
+                              "what": "reference JaT_AudioSR_V3 fp32 eval forward, B=2 / B=1, T=512, survey container"}
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a torch.distributed.run CHILD process (this parent
+    never touches the GPU: no exec of an initialised process), stream their output through and return rank 0's JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               JAT_BENCH_CHILD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit(f"bench ranks failed (exit {rc}); no result line")
+    print(line)
+
+
+def dry_run(args):
+    """CPU rehearsal of the multi-rank contract (gloo): barrier + timed K stand-in steps + MAX over ranks + one JSON line
+    from rank 0.  No GPU, no kernel: checks the launcher and the distributed plumbing only."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from jatsr_amd.dist import max_over_ranks, shard_range
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    a, b = shard_range(args.B, world, rank) if args.scaling == "strong" else (0, args.B)
+    x = np.ones((b - a, 64), np.float32)
+
+    def step():
+        return float((x @ x.T).sum())
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t1)
+    seen = world
+    if world > 1:
+        t = torch.tensor([1.0])
+        dist.all_reduce(t)
+        seen = int(t.item())
+    total_b = args.B if args.scaling == "strong" else world * args.B
+    if rank == 0:
+        print(json.dumps({"metric": "DiT latent-frames/sec (B=28,C=1024,T=512, 50-step CFG)", "value": total_b * args.T * args.steps / elapsed,
+                          "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": seen,
+                          "config": {"workload": "launcher rehearsal on CPU (gloo), stand-in step", "B_local": b - a}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -51,7 +129,15 @@ def main():
                     help="train: time K DDP training steps on every rank instead (configs[3]; not the headline metric)")
     ap.add_argument("--train-T", type=int, default=1378)
     ap.add_argument("--latent-loss", type=float, default=0.3, help="--mode train: latent perceptual loss weight (0 = MSE)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: B per GPU fixed; strong: one batch of B sharded over the GPUs (dist.shard_range)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the launcher and timing contract (tests)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])     # before anything touches a GPU
+    if args.dry_run:
+        return dry_run(args)
 
     import numpy as np
     import torch
@@ -64,8 +150,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     L.require_gpu()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -76,6 +161,15 @@ def main():
 
     cfg = recipe.CONFIGS[args.config]
     B, T, C_lat = args.B, args.T, cfg["input_channels"]
+    from jatsr_amd.dist import shard_range
+    if args.scaling == "strong" and args.mode == "sample":      # one batch of B, rank r takes rows [a, b)
+        a_, b_ = shard_range(args.B, world, rank)
+        B = b_ - a_
+    ranks_seen = world
+    if dist is not None:                                          # the ranks RCCL actually connected
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
     t0 = time.time()
     sd = recipe.make_state_dict(cfg)
     model = jatsr_amd.JaT_AudioSR_V3(**cfg, dropout=0.1, drop_path_rate=0.05)   # training-only rates, train_ddp_v3m2.py:82-83
@@ -145,7 +239,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert bool(torch.isfinite(out).all()), "sampler produced non-finite values"
-    frames = world * B * T * args.steps
+    total_B = args.B if args.scaling == "strong" else world * B
+    frames = total_B * T * args.steps
     value = frames / elapsed
 
     fwd_flops_B = recipe.forward_flops(cfg, B, T)   # algorithmic FLOPs, SURVEY.md §8d closed form
@@ -156,12 +251,17 @@ def main():
     result = {
         "metric": "DiT latent-frames/sec (B=28,C=1024,T=512, 50-step CFG)",
         "value": value, "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.config} DiT {args.num_steps}-step CFG={args.cfg_scale} flow-matching sampling, "
-                               f"{'hipGraph' if use_graph else 'eager'}, B={B}/GPU C={C_lat} T={T}",
-                   "B_per_gpu": B, "T": T, "C": C_lat, "euler_steps": args.num_steps, "cfg_scale": args.cfg_scale,
-                   "weights": "recipe (random-init, non-zero adaLN/final)", "parallelism": f"replicas x{world}"},
+                               f"{'hipGraph' if use_graph else 'eager'}, "
+                               + (f"B={B}/GPU" if args.scaling == "weak" else f"one batch of B={args.B} sharded "
+                                  f"{[shard_range(args.B, world, r)[1] - shard_range(args.B, world, r)[0] for r in range(world)]}")
+                               + f" C={C_lat} T={T}",
+                   "B_per_gpu": B if args.scaling == "weak" else None, "global_batch": total_B, "T": T, "C": C_lat,
+                   "euler_steps": args.num_steps, "cfg_scale": args.cfg_scale,
+                   "weights": "recipe (random-init, non-zero adaLN/final)",
+                   "parallelism": f"replicas x{world}, no collective in the loop", "rccl_ranks": ranks_seen},
         "sampler_mfma_frac": sampler_tflops / PEAK_BF16_TFLOPS,
         "sampler_tflops_per_gpu": sampler_tflops,
         "setup_s": setup_s,
@@ -224,7 +324,7 @@ def main():
         ach = g_flops / (g_ms * 1e-3) / 1e12
         traffic = None   # L2-miss bytes per launch from the committed PMC passes (same kernel, same shape), if any
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")))
             traffic = pmc.get(f"fc1_variant{var.value}_M{Mg}_N{Ng}_K{Kg}", {}).get("traffic_bytes")
         except Exception:
             pass
@@ -232,8 +332,10 @@ def main():
                                         f"M={Mg} N={Ng} K={Kg}",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-                              "traffic_note": "bytes/launch = (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01/pmc_traffic.json "
-                                              "(separate --pmc passes; fabric-side, Infinity-Cache hits included)",
+                              "traffic_note": "bytes/launch = (2*FETCH_SIZE+WRITE_SIZE)*1024 of THIS kernel variant and shape from "
+                                              "profiles/r02/pmc_traffic.json (separate rocprofv3 --pmc passes of this build, "
+                                              "tools/pmc_traffic.sh; fabric-side: Infinity-Cache hits included); null if the "
+                                              "variant/shape has no committed pass",
                               "flops_per_launch": g_flops, "avg_launch_ms": g_ms, "launches_timed": n_l.value}
 
         # ---- training step (BASELINE configs[3]; train_ddp_v3m2.py:533-622): forward + MSE + backward + clip + AdamW on
@@ -270,17 +372,32 @@ def main():
                                                 "as train_ddp_v3m2.py:82-83; *_latent_loss: MSE + 0.3 x latent "
                                                 "perceptual loss of train_ddp_v3mod2.py (configs[3]); one GPU", **legs}
 
-        # ---- CPU baseline: numpy oracle (port of the reference fp32 CPU forward) on a bounded sample --------
+        # ---- CPU baseline: the numpy oracle (port of the reference's fp32 CPU forward, pinned to the
+        # reference by tests/golden) on this host's cores: 1 warm-up + 3 timed forwards at B=28, T=512, and the oracle's
+        # 50-step CFG sampler loop at B=2 time-boxed to its first steps (a full CPU run is ~20 min) and labelled as scaled.
         if world == 1 and not args.no_cpu_baseline:
             from oracle import jat_oracle as O
             from threadpoolctl import threadpool_limits
-            cores = min(os.cpu_count() or 1, 32)     # BLAS threads actually used (more only oversubscribes)
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            cores = min(avail, 32)     # BLAS threads actually used (beyond 32 the fp32 GEMMs of this size only oversubscribe)
             threadpool_limits(limits=cores)
+            cpu_model = "unknown"
+            try:
+                for ln in open("/proc/cpuinfo"):
+                    if ln.startswith("model name"):
+                        cpu_model = ln.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
             orc = O.OracleModel(cfg, sd, "rms", np.float32)
-            Bc = 2
-            xs, xc = recipe.make_latents(Bc, C_lat, T, salt=5)
-            tc = np.array([0.3, 0.7], np.float32)[:Bc]
-            orc.forward(xs, tc, xc)
+            xs2, xc2 = recipe.make_latents(2, C_lat, T, salt=5)
+            orc.forward(xs2, np.array([0.3, 0.7], np.float32), xc2)            # warm-up (BLAS threads, page faults)
+            Bc = args.B
+            xs, xc = recipe.make_latents(Bc, C_lat, T, salt=6)
+            tc = np.linspace(0.02, 0.98, Bc).astype(np.float32)
             reps = 3
             c0 = time.perf_counter()
             for _ in range(reps):
@@ -288,12 +405,24 @@ def main():
             c_s = (time.perf_counter() - c0) / reps
             fwd_fps = Bc * T / c_s
             per_run = (2 if use_cfg else 1) * args.num_steps
+            # the sampler loop itself (CFG double batch, combine, Euler update) on 2 samples, first steps only
+            box_steps = 2
+            lr2, z2 = recipe.gaussian("lr_latent", (2, C_lat, T), 1234), recipe.gaussian("z0", (2, C_lat, T), 1235)
+            s0 = time.perf_counter()
+            O.flow_matching_sample(orc, lr2, z2, args.num_steps, args.cfg_scale, max_steps=box_steps)
+            s_s = (time.perf_counter() - s0) / box_steps                          # seconds per Euler step at B=2
+            smp_fps = 2 * T / (s_s * args.num_steps)
             result["cpu_baseline"] = {
-                "value": fwd_fps / per_run, "unit": "latent-frames/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} timed fp32 numpy-oracle forwards at B={Bc},T={T} after 1 warm-up "
-                          f"({c_s:.2f} s each, {fwd_fps:.0f} forward-frames/s); sampler rate = forward rate / {per_run} "
-                          f"({args.num_steps} steps x CFG double batch) — scaled, the full CPU run (~20 min) is not executed",
-                "forward_latent_frames_per_s": fwd_fps}
+                "value": smp_fps, "unit": "latent-frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+                "host_cores_available": avail,
+                "sample": f"oracle 50-step CFG={args.cfg_scale} sampler at B=2,T={T}: first {box_steps} of {args.num_steps} "
+                          f"Euler steps timed ({s_s:.2f} s per step, CFG double batch) and scaled to the full run "
+                          f"(time-boxed: a complete CPU run is ~{s_s * args.num_steps / 60 * 14:.0f} min at B=28); "
+                          f"forward: 1 warm-up + {reps} timed fp32 numpy-oracle forwards at B={Bc},T={T} ({c_s:.2f} s each)",
+                "forward_latent_frames_per_s": fwd_fps,
+                "forward_gflops": fwd_flops_B / c_s / 1e9,
+                "sampler_from_forward_rate": fwd_fps / per_run,
+                "reference_torch_cpu_survey": REFERENCE_TORCH_CPU_SURVEY}
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

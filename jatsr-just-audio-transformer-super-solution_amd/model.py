@@ -60,6 +60,7 @@ class _Handle:
         self.ptr = C.c_void_p()
         self.version = None
         self.epoch = 0          # bumped when a trainer updates the weights in place (invalidates cached samplers)
+        self.trainer = None     # weakref to the attached jatsr_amd.Trainer (its transposed operand copies follow a re-pack)
         self.device = None
         self._ws = None
         c = L.JatConfig(cfg["input_channels"], cfg["cond_channels"], cfg["patch_len"], cfg["hidden_size"],
@@ -124,6 +125,9 @@ class _PackedMixin:
             h.load(named)
             h.version = ver
             h.device = dev
+            tr = h.trainer() if h.trainer is not None else None
+            if tr is not None:        # e.g. model.load_state_dict() while a Trainer is attached: its W^T copies are stale too
+                tr._weights_replaced()
         return h
 
 

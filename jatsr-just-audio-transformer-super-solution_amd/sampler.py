@@ -21,16 +21,26 @@ class Sampler:
     def __init__(self, model, B, T, num_steps=50, cfg_scale=1.0):
         self.model = model
         self.B, self.T, self.steps, self.cfg_scale = int(B), int(T), int(num_steps), float(cfg_scale)
-        h = model._get_handle()
+        self.ptr = C.c_void_p()
+        self._build()
+
+    def _build(self):
+        """(Re)create the C-side sampler: modulation table, per-step folded weights and the captured graph all depend on
+        the model's weights as they are NOW."""
+        self._destroy()
+        h = self.model._get_handle()
         self._handle = h
         self._version = (h.version, getattr(h, "epoch", 0))   # epoch: bumped by jatsr_amd.train after every weight update
-        self.ptr = C.c_void_p()
         L.check(L.lib().jat_sampler_create(h.ptr, self.B, self.T, self.steps, self.cfg_scale, C.byref(self.ptr)))
+
+    def _destroy(self):
+        if self.ptr:
+            L.lib().jat_sampler_destroy(self.ptr)
+            self.ptr = C.c_void_p()
 
     def __del__(self):
         try:
-            if self.ptr:
-                L.lib().jat_sampler_destroy(self.ptr)
+            self._destroy()
         except Exception:
             pass
 
@@ -40,6 +50,11 @@ class Sampler:
         if tuple(lr_latent.shape) != (self.B, self.model.input_channels, self.T) or z0.shape != lr_latent.shape:
             raise ValueError(f"sampler bucket is [B={self.B}, C={self.model.input_channels}, T={self.T}], got "
                              f"lr {tuple(lr_latent.shape)} z0 {tuple(z0.shape)}")
+        # a sampler held across Trainer.optimizer_step / load_checkpoint / load_state_dict would mix the OLD modulation table
+        # and folded weights with the NEW packed weights: rebuild it instead
+        h = self.model._get_handle()
+        if (h.version, getattr(h, "epoch", 0)) != self._version:
+            self._build()
         out = torch.empty_like(z0)
         L.check(L.lib().jat_sampler_run(self.ptr, L.ptr(lr_latent), L.ptr(z0), L.ptr(out), 1 if use_graph else 0,
                                         L.stream_ptr()))

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 
 import torch
 
@@ -84,14 +85,16 @@ class GradScaler:
 
 
 def allreduce_mean_(flat, group=None):
-    """Sum `flat` over the ranks of `group` in place and return the divisor the caller still has to apply (the
-    world size): the division is folded into the optimiser's unscale factor instead of a second pass over 3 GB."""
+    """Sum `flat` over the ranks of `group` in place (reduce-scatter + all-gather, `dist.exchange_sum_`) and return the
+    divisor the caller still has to apply (the world size): the division is folded into the optimiser's unscale factor
+    instead of a second pass over 3 GB."""
     import torch.distributed as dist
+    from .dist import exchange_sum_
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world = dist.get_world_size(group)
     if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        exchange_sum_(flat, group)
     return world
 
 
@@ -120,14 +123,22 @@ class Trainer:
         self.scaler = GradScaler(enabled=use_grad_scaler)
         self.group = process_group
         self.distributed = bool(distributed)
-        self.global_step = 0
+        self.global_step = 0     # every call of optimizer_step (LR schedule, mask seed, checkpoint: train_ddp_v3m2.py:634)
+        self.opt_step = 0        # optimiser steps actually taken (AdamW bias correction; skipped when the scaler finds inf)
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise L.JatError("move the model to the GPU first (.to('cuda')); there is no CPU fallback")
         self.device = dev
+        prev = model.__dict__.get("_jat_trainer")
+        if prev is not None and prev() is not None:
+            prev()._detached = True      # the model's parameters move to THIS trainer's flat buffer: the old one must not step
+        self._detached = False
+        import torch.distributed as dist
+        rank = dist.get_rank(process_group) if (distributed and dist.is_available() and dist.is_initialized()) else 0
         self.gen = torch.Generator(device=dev)
-        if seed is not None:
-            self.gen.manual_seed(seed)
+        # seed=None: decorrelate the ranks' draws of t / noise / CFG mask (each DDP process of the reference has its own
+        # generator state); an explicit seed is used as given — pass seed + rank for per-rank streams
+        self.gen.manual_seed(seed if seed is not None else 0x5EED0000 + rank)
         # ---- flat fp32 buffers; the model's parameters become views of `params` --------------------------------
         named = [(k, p) for k, p in model.named_parameters()]
         self.layout, total = flat_layout([(k, p.shape) for k, p in named])
@@ -139,8 +150,15 @@ class Trainer:
             view = self.params[off:off + n].view(shape)
             view.copy_(p.data.float())
             p.data = view
+        if self._dist_on() and self._world() > 1:
+            # DDP broadcasts rank 0's parameters at construction (train_ddp_v3m2.py:512): without it freshly built
+            # replicas start from different random weights and never converge to each other
+            dist.broadcast(self.params, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
         h = model._get_handle()          # packs the (now flat-backed) weights
         self._handle = h
+        h.trainer = weakref.ref(self)
+        model.__dict__["_jat_trainer"] = weakref.ref(self)
         refs = (L.JatTensorRef * len(self.layout))()
         self._keep = []
         for i, (k, off, n, _) in enumerate(self.layout):
@@ -169,6 +187,11 @@ class Trainer:
         self._hook = L.GRAD_HOOK(self._on_grads_ready)          # keep the ctypes thunk alive
         L.check(L.lib().jat_trainer_set_grad_hook(self.ptr, C.cast(self._hook, C.c_void_p), None))
 
+    def _check_attached(self):
+        if self._detached:
+            raise L.JatError("this Trainer was superseded: a newer Trainer owns the model's parameters (they are views of "
+                             "the newer trainer's flat buffer)")
+
     def _dist_on(self):
         import torch.distributed as dist
         return self.distributed and dist.is_available() and dist.is_initialized()
@@ -183,11 +206,15 @@ class Trainer:
             return
         if self._world() == 1 and self.overlap != "force":
             return
+        from .dist import exchange_sum_
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(ev)
-            self._pending.append(dist.all_reduce(self.grads[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self._world() == 1:     # overlap == "force": exercise the hook machinery with a 1-rank collective
+                self._pending.append(dist.all_reduce(self.grads[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:                      # reduce-scatter + all-gather of this slice over all xGMI links
+                self._pending.extend(exchange_sum_(self.grads[off:off + n], self.group, async_op=True))
         self._covered += n
 
     def loss_terms(self):
@@ -267,6 +294,8 @@ class Trainer:
             if tuple(x.shape) != (self.B, self.model.input_channels, self.T) or x.dtype != torch.float32 or not x.is_cuda:
                 raise ValueError(f"expected fp32 CUDA [{self.B}, {self.model.input_channels}, {self.T}], got "
                                  f"{tuple(x.shape)} {x.dtype} on {x.device}")
+        self._check_attached()
+        self.model._get_handle()     # parameters overwritten through PyTorch (load_state_dict)? re-pack, incl. this trainer's copies
         pred = torch.empty_like(z_t) if want_pred else None
         self._pending, self._covered = [], 0
         L.check(L.lib().jat_trainer_fwd_bwd(self.ptr, L.ptr(z_t.contiguous()), L.ptr(t.contiguous()), L.ptr(cond.contiguous()),
@@ -281,6 +310,7 @@ class Trainer:
     def optimizer_step(self, lr=None):
         """All-reduce, unscale, clip_grad_norm_(grad_clip), AdamW, re-pack.  Returns (loss, grad_norm) as floats —
         the one host synchronisation of the step, like the reference's `.item()` calls (train_ddp_v3m2.py:615,622)."""
+        self._check_attached()
         if self._pending:          # slices were reduced under the backward: the step's stream waits for the last of them
             for w in self._pending:
                 w.wait()
@@ -294,13 +324,14 @@ class Trainer:
         scale = self.scaler.scale * world
         L.check(L.lib().jat_trainer_optim(self.ptr, float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                           float(self.weight_decay), float(self.grad_clip or 0.0), float(scale),
-                                          self.global_step + 1, C.c_void_p(self._scal.data_ptr() + 4), L.stream_ptr()))
+                                          self.opt_step + 1, C.c_void_p(self._scal.data_ptr() + 4), L.stream_ptr()))
         loss, gnorm = self._scal.tolist()
         gnorm /= scale
-        found_inf = not math.isfinite(gnorm)
+        found_inf = not math.isfinite(gnorm)    # the same on every rank: the norm is taken over the all-reduced gradients
         self.scaler.update(found_inf)
+        self.global_step += 1                   # counts batches, skipped or not (train_ddp_v3m2.py:634)
         if not found_inf:
-            self.global_step += 1
+            self.opt_step += 1
             self._handle.epoch += 1      # the weights changed under the model: cached samplers (mod tables, graphs) are stale
         self.last_lr = lr
         return loss, gnorm
@@ -363,13 +394,13 @@ class Trainer:
         """torch.optim.AdamW.state_dict() layout, so that the reference trainer can resume from it."""
         state = {}
         for i, (k, off, n, shape) in enumerate(self.layout):
-            state[i] = dict(step=torch.tensor(float(self.global_step)),
+            state[i] = dict(step=torch.tensor(float(self.opt_step)),
                             exp_avg=self.exp_avg[off:off + n].view(shape).clone(),
                             exp_avg_sq=self.exp_avg_sq[off:off + n].view(shape).clone())
         group = dict(lr=getattr(self, "last_lr", self.base_lr), betas=tuple(self.betas), eps=self.eps,
                      weight_decay=self.weight_decay, amsgrad=False, maximize=False, foreach=None, capturable=False,
                      differentiable=False, fused=None, params=list(range(len(self.layout))))
-        return dict(state=state if self.global_step > 0 else {}, param_groups=[group])
+        return dict(state=state if self.opt_step > 0 else {}, param_groups=[group])
 
     def load_optimizer_state_dict(self, sd):
         for i, (k, off, n, shape) in enumerate(self.layout):
@@ -378,7 +409,7 @@ class Trainer:
                 continue
             self.exp_avg[off:off + n].view(shape).copy_(st["exp_avg"].to(self.device, torch.float32))
             self.exp_avg_sq[off:off + n].view(shape).copy_(st["exp_avg_sq"].to(self.device, torch.float32))
-            self.global_step = int(float(st["step"]))
+            self.opt_step = int(float(st["step"]))       # AdamW's own counter: bias correction resumes where it stopped
 
     def save_checkpoint(self, path, epoch=0, best_val_loss=float("inf")):
         ck = dict(epoch=epoch, global_step=self.global_step, best_val_loss=best_val_loss,
@@ -403,7 +434,14 @@ class Trainer:
             self.load_optimizer_state_dict(checkpoint["optimizer_state_dict"])
         if checkpoint.get("scaler_state_dict") and self.scaler.enabled:
             self.scaler.load_state_dict(checkpoint["scaler_state_dict"])
-        self.global_step = int(checkpoint.get("global_step", self.global_step))
-        L.check(L.lib().jat_trainer_repack(self.ptr, L.stream_ptr()))   # every operand copy follows the new weights
-        self._handle.epoch += 1
+        self.global_step = int(checkpoint.get("global_step", self.opt_step))
+        self._weights_replaced()
         return checkpoint.get("epoch", 0)
+
+    def _weights_replaced(self):
+        """The fp32 master weights were overwritten from outside an optimiser step (checkpoint, load_state_dict): rebuild
+        every operand copy (bf16, transposed) and make dependants stale.  Synchronous: a sampler created next builds its
+        tables on a private stream and must see the finished copies."""
+        L.check(L.lib().jat_trainer_repack(self.ptr, L.stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+        self._handle.epoch += 1

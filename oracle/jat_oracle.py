@@ -232,16 +232,17 @@ def linspace_f32(a, b, n):
     return out
 
 
-def flow_matching_sample(model, lr_latent, z0, num_steps=50, cfg_scale=1.0):
+def flow_matching_sample(model, lr_latent, z0, num_steps=50, cfg_scale=1.0, max_steps=None):
     """flow_matching_sample — infer_test_v3m2.py:107-185, with the initial noise `z0` supplied by the
-    caller instead of torch.randn (:133) so that results are reproducible across devices."""
+    caller instead of torch.randn (:133) so that results are reproducible across devices.
+    max_steps: stop after that many Euler steps of the `num_steps` schedule (bench.py's time-boxed CPU baseline)."""
     dt_ = model.dtype
     lr = np.asarray(lr_latent).astype(dt_)
     z = np.asarray(z0).astype(dt_).copy()
     B = lr.shape[0]
     ts = linspace_f32(0.0, 1.0, num_steps + 1)
     use_cfg = cfg_scale != 1.0                                            # :139
-    for i in range(num_steps):
+    for i in range(num_steps if max_steps is None else min(num_steps, max_steps)):
         t_curr, t_next = ts[i], ts[i + 1]
         dt = np.float32(t_next - t_curr)
         tb = np.full((B,), t_curr, dtype=np.float32)

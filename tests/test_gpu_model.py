@@ -292,8 +292,9 @@ def test_sample_long_at_v3mod2_dims_batched_equals_chunk_by_chunk():
     r = rel_l2(g, ref)
     print(f"sample_long v3mod2 T=4096: batched vs chunk-by-chunk rel-L2 {r:.3e}")
     assert r < 1e-2
-    # the short last chunk is its own bucket in both runs: its un-faded tail is bit-identical
-    assert np.array_equal(g[:, :, 3618 + 172:], outs[3][:, :, 172:])
+    # the short last chunk is its own bucket in both runs: its un-faded tail differs only by the de-normalisation's
+    # rounding (fused multiply-add in jat_channel_affine vs torch's mul + add)
+    assert np.allclose(g[:, :, 3618 + 172:], outs[3][:, :, 172:], rtol=0, atol=4e-6)
 
 
 def test_graph_replay_is_deterministic():

@@ -36,7 +36,7 @@ def gsub(a, meta):
     s = meta["strides"]
     a = np.asarray(a)
     if a.size <= meta["full_limit"] or a.ndim != 2:
-        return a if a.size <= meta["full_limit"] else a.reshape(-1)[::s[0] * s[1]]
+        return a if a.size <= meta["full_limit"] else a.reshape(-1)[::(meta.get("stride1d") or s[0] * s[1])]
     return a[::s[0], ::s[1]]
 
 
@@ -543,3 +543,84 @@ def test_sampler_follows_trained_weights():
     m2.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, strict=False)
     c = jatsr_amd.flow_matching_sample(m2.to("cuda").eval(), lr, num_steps=4, cfg_scale=3.0, verbose=False, z0=z0)
     assert torch.equal(b, c)
+
+
+def test_held_sampler_and_checkpoint_resume_follow_the_weights(tmp_path):
+    """(i) a `Sampler` object the caller HOLDS across an optimiser step must not mix its old modulation table /
+    folded weights with the new packed weights — `run` rebuilds it; (ii) `load_checkpoint` followed immediately by sampling
+    (tables are built on the sampler's private stream) equals a from-scratch model with the same weights bit for bit;
+    (iii) `model.load_state_dict` while a Trainer is attached also refreshes the trainer's transposed operand copies."""
+    import jatsr_amd
+    z, meta = load_golden("train_micro_T24")
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    B, C, T = hr.shape
+    s = jatsr_amd.Sampler(m, B, T, 4, 3.0)
+    a = s.run(lr, noise)
+    tr.base_lr = 1e-2
+    mean, std = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    tr.train_step(hr, lr, mean, std, mean, std)
+    b = s.run(lr, noise)                                   # same object, new weights
+    assert not torch.equal(a, b)
+
+    def fresh_copy(model):
+        m2 = type(model)(**recipe.CONFIGS[meta["cfg"]], dropout=0.0, drop_path_rate=0.0)
+        m2.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=False)
+        return m2.to("cuda").eval()
+    assert torch.equal(b, jatsr_amd.Sampler(fresh_copy(m), B, T, 4, 3.0).run(lr, noise))
+    # (ii) resume into a trainer with different weights, sample at once
+    path = str(tmp_path / "ck.pt")
+    tr.save_checkpoint(path)
+    m3, tr3 = make_trainer(dict(meta, salt=meta["salt"] + 5), use_grad_scaler=False, condition_noise_ratio=0.0)
+    s3 = jatsr_amd.Sampler(m3, B, T, 4, 3.0)
+    before = s3.run(lr, noise)
+    tr3.load_checkpoint(path)
+    after = s3.run(lr, noise)
+    assert not torch.equal(before, after) and torch.equal(after, b)
+    # (iii) load_state_dict under an attached trainer: the next training step uses W^T of the NEW weights
+    m4, tr4 = make_trainer(dict(meta, salt=meta["salt"] + 7), use_grad_scaler=False, condition_noise_ratio=0.0)
+    m4.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()}, strict=False)
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    tr.forward_backward(z_t, t2, cond, hr, mask_seed=5)
+    tr4.forward_backward(z_t, t2, cond, hr, mask_seed=5)
+    assert torch.equal(tr4.grads, tr.grads)
+
+
+def test_second_trainer_supersedes_the_first_and_batch_cap_is_reported():
+    """A second Trainer on the same model takes over the parameters (views of ITS flat buffer); the first one refuses to
+    step instead of updating orphaned buffers.  jat_trainer_create rejects a per-rank batch above 32 (include/jat_hip.h)."""
+    z, meta = load_golden("train_micro_T24")
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    tr2 = Trainer(m, batch_size=meta["B"], frames=meta["T"], use_grad_scaler=False)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    z_t, t2, cond = tr2.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    tr2.forward_backward(z_t, t2, cond, hr)
+    with pytest.raises(L.JatError):
+        tr.forward_backward(z_t, t2, cond, hr)
+    with pytest.raises(L.JatError):
+        tr.optimizer_step()
+    with pytest.raises(ValueError):
+        Trainer(m, batch_size=33, frames=meta["T"])
+
+
+def test_skipped_step_advances_the_schedule_counter_not_adamw():
+    """train_ddp_v3m2.py:634 increments global_step every batch; AdamW's own step (bias correction) only counts updates that
+    happened.  A non-finite gradient (scaler skip) must advance the first and not the second, and the checkpoint stores both."""
+    z, meta = load_golden("train_micro_T24")
+    m, tr = make_trainer(meta, use_grad_scaler=True, condition_noise_ratio=0.0)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    tr.forward_backward(z_t, t2, cond, hr)
+    tr.optimizer_step(lr=1e-4)
+    assert (tr.global_step, tr.opt_step) == (1, 1)
+    seed1 = tr.step_seed()
+    bad = hr.clone()
+    bad[0, 0, 0] = float("inf")
+    tr.forward_backward(z_t, t2, cond, bad)
+    _, gn = tr.optimizer_step(lr=1e-4)
+    assert not math.isfinite(gn) and (tr.global_step, tr.opt_step) == (2, 1)
+    assert tr.step_seed() != seed1                          # a retried batch draws fresh dropout masks
+    sd = tr.optimizer_state_dict()
+    assert float(sd["state"][0]["step"]) == 1.0
+    ck = tr.save_checkpoint("/tmp/_jat_ck_counters.pt")
+    assert ck["global_step"] == 2

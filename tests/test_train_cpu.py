@@ -20,7 +20,7 @@ def gsub(a, meta):
     s = meta["strides"]
     a = np.asarray(a)
     if a.size <= meta["full_limit"] or a.ndim != 2:
-        return a if a.size <= meta["full_limit"] else a.reshape(-1)[::s[0] * s[1]]
+        return a if a.size <= meta["full_limit"] else a.reshape(-1)[::(meta.get("stride1d") or s[0] * s[1])]
     return a[::s[0], ::s[1]]
 
 
@@ -167,6 +167,48 @@ def test_gradient_allreduce_world2_gloo():
     assert T.allreduce_mean_(torch.ones(4)) == 1       # no process group: identity
 
 
+def _exchange_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from jatsr_amd.dist import exchange_sum_
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for n, mode in ((4096, "sync"), (4096 + 64, "async"), (1001, "fallback")):   # 1001 % 2 != 0: one all_reduce instead
+        g = torch.Generator().manual_seed(100 + rank)
+        buf = torch.randn(n, generator=g)
+        ref = buf.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        works = exchange_sum_(buf, None, async_op=(mode == "async"))
+        for w in works:
+            w.wait()
+        res[mode] = (bool(torch.equal(buf, ref)), float(buf.double().sum()))
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_reduce_scatter_all_gather_world2_gloo():
+    """The xGMI-shaped gradient exchange (jatsr_amd.dist.exchange_sum_): reduce-scatter of the rank's shard + all-gather,
+    in place, equals the all-reduce bit for bit (two addends: order-free), on both ranks, sync and async forms; a length
+    that does not divide by the world size takes the all_reduce fallback."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for mode in ("sync", "async", "fallback"):
+        assert got[0][mode][0] and got[1][mode][0], mode
+        assert got[0][mode][1] == got[1][mode][1], mode       # replicas hold identical sums
+
+
 def _loss_inputs(meta):
     B, C, Tn, salt = meta["B"], meta["C"], meta["T"], meta["salt"]
     pred = recipe.gaussian("loss_pred", (B, C, Tn), salt + 400)
@@ -189,7 +231,8 @@ def test_latent_loss_oracle_matches_reference_classes(name):
     assert rel_l2(dpred, z["dpred"]) <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["train_micro_mod2_T24", "train_tiny_mod2_T128"])
+@pytest.mark.parametrize("name", ["train_micro_mod2_T24", "train_tiny_mod2_T128", "train_micro_mod2fw0_T24",
+                                  "train_tiny_mod2fw0_T128"])
 def test_train_oracle_v3mod2_step_matches_reference(name):
     """LayerNorm model + MSE + latent perceptual loss with the clean LR latent (train_ddp_v3mod2.py:854-896)."""
     z, meta = load_golden(name)
