@@ -579,7 +579,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
     }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
-#ifdef JAT_DEV_VARIANTS   // timing ablations (wrong results): dbg bit 1: no DMA after the prologue, bit 2: no fragment reads
+#ifdef JAT_ABLATE   // timing ablations (wrong results; -DJAT_ABLATE builds only): dbg bit 1: no DMA after the prologue, bit 2: no fragment reads
     const bool abl_dma = p.dbg & 2, abl_rd = p.dbg & 4, abl_mma = p.dbg & 8;   // after K-tile 0, bit 3: no MFMAs
 #else
     constexpr bool abl_dma = false, abl_rd = false, abl_mma = false;
@@ -729,6 +729,108 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
 
   const int nw0 = n0 + wn * TN * 16;  // wave-uniform first column
 
+  // ---- split-residual epilogue (sampler with folded norms).  The residual stream lives as TWO bf16 planes, x = hi + lo with
+  // hi = bf16(x), lo = bf16(x - hi): 16 significant bits (an update costs 2^-17 relative, two orders below the bf16 rounding of
+  // the GEMM operands), the same 4 bytes per element as fp32 — and `hi` IS the bf16 A operand of the next GEMM (whose
+  // folded weights carry the norm weight and the adaLN scale), so the epilogue writes no extra copy and no norm kernel runs.
+  //   EPI_RESID: x_new = (hi + lo) + gate[b][n] * (acc + bias)      EPI_F32: x_new = acc + bias
+  // plus the row partial sums of x_new^2 over this wave's columns (the consumer's rstd), in fixed order.
+  // Accumulators go through the wave-private LDS slab so that every global access is 16 B per lane along a row.
+  if constexpr (CE && (EPI == EPI_RESID || EPI == EPI_F32)) {
+    if (p.fold_out != nullptr) {
+      constexpr int RS = TN * 64 + 16;         // slab row: TN*16 fp32 + pad
+      constexpr int CPR8 = TN * 2;             // 8-element chunks per row
+      constexpr int NCH8 = 32 * CPR8 / 64;     // chunks per lane per 32-row group (= TN)
+      static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
+      __builtin_amdgcn_s_barrier();            // every wave is done reading the staging buffers
+      if (p.dbg & 1) return;
+      char* wbuf = smem + wave * (32 * RS);
+      const int mw0 = m0 + wm * TM * 16;
+      float4 bb[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+      auto up = [](unsigned u, float& a, float& b) { a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u); };
+#pragma unroll
+      for (int ig = 0; ig < (TM + 1) / 2; ++ig) {
+        const int grows = (2 * ig + 1 < TM) ? 32 : 16;
+        // residual / gate loads of the whole group first (independent of the slab): in flight under the slab writes
+        [[maybe_unused]] uint4 hi[NCH8], lo[NCH8];
+        [[maybe_unused]] float4 g0[NCH8], g1[NCH8];
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+          for (int t = 0; t < NCH8; ++t) {
+            const int c = lane + 64 * t, row = min(c / CPR8, grows - 1), cc = c - (c / CPR8) * CPR8;
+            const int m = min(mw0 + ig * 32 + row, p.M - 1), n = nw0 + cc * 8;
+            hi[t] = *(const uint4*)(p.fold_out + (int64_t)m * p.ldo + n);
+            lo[t] = *(const uint4*)(p.fold_lo + (int64_t)m * p.ldo + n);
+            const float* gp = p.gate + (int64_t)(m / p.ntok) * p.gate_bstride + n;
+            g0[t] = *(const float4*)gp;
+            g1[t] = *(const float4*)(gp + 4);
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) if (2 * ig + ii < TM) {
+            f32x4 v = acc[2 * ig + ii < TM ? 2 * ig + ii : 0][j] * rstd_rows[2 * ig + ii < TM ? 2 * ig + ii : 0];
+            *(float4*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 4) =
+                float4{v[0] + bb[j].x, v[1] + bb[j].y, v[2] + bb[j].z, v[3] + bb[j].w};
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NCH8; ++t) {
+          const int c = lane + 64 * t, row = c / CPR8, cc = c - row * CPR8;
+          const int m = mw0 + ig * 32 + row, n = nw0 + cc * 8;
+          char* slot = wbuf + (row < 32 ? row : 0) * RS + cc * 32;
+          const float4 a0 = *(const float4*)slot, a1 = *(const float4*)(slot + 16);
+          float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          if constexpr (EPI == EPI_RESID) {
+            const unsigned hw[4] = {hi[t].x, hi[t].y, hi[t].z, hi[t].w}, lw[4] = {lo[t].x, lo[t].y, lo[t].z, lo[t].w};
+            const float gg[8] = {g0[t].x, g0[t].y, g0[t].z, g0[t].w, g1[t].x, g1[t].y, g1[t].z, g1[t].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float h0, h1, l0, l1;
+              up(hw[e], h0, h1);
+              up(lw[e], l0, l1);
+              x[2 * e] = (h0 + l0) + gg[2 * e] * x[2 * e];
+              x[2 * e + 1] = (h1 + l1) + gg[2 * e + 1] * x[2 * e + 1];
+            }
+          }
+          unsigned ho[4], lw2[4];
+          float sq = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned short ha = f2bf(x[2 * e]), hb = f2bf(x[2 * e + 1]);
+            ho[e] = (unsigned)ha | ((unsigned)hb << 16);
+            const float ra = x[2 * e] - __uint_as_float((unsigned)ha << 16), rb = x[2 * e + 1] - __uint_as_float((unsigned)hb << 16);
+            lw2[e] = (unsigned)f2bf(ra) | ((unsigned)f2bf(rb) << 16);
+            sq += x[2 * e] * x[2 * e] + x[2 * e + 1] * x[2 * e + 1];
+          }
+          const bool live = row < grows && m < p.M;
+          if (live) {
+            *(uint4*)(p.fold_out + (int64_t)m * p.ldo + n) = uint4{ho[0], ho[1], ho[2], ho[3]};
+            *(uint4*)(p.fold_lo + (int64_t)m * p.ldo + n) = uint4{lw2[0], lw2[1], lw2[2], lw2[3]};
+          }
+          if (row < 32) *(float*)slot = live ? sq : 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {  // row partial sums over this wave's columns: two lanes per row, fixed order
+          constexpr int HALF = CPR8 / 2;
+          const int r = lane >> 1, h = lane & 1;
+          float sq = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < HALF; ++cc) sq += *(const float*)(wbuf + r * RS + (h * HALF + cc) * 32);
+          sq += __shfl_xor(sq, 1);
+          const int m = mw0 + ig * 32 + r;
+          if (h == 0 && m < p.M && r < grows) p.fold_part[(int64_t)m * p.fold_np + nw0 / (TN * 16)] = sq;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
+  }
+
   // ---- coalesced epilogue (CE): accumulators -> wave-private LDS slab (32 rows at a time) -> each lane
   // reads back 16 B that are CONTIGUOUS along n, so global loads/stores cover whole rows of the wave tile
   // (full 128-B lines) instead of 8-16 B per lane at a row stride.
@@ -749,7 +851,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
-    [[maybe_unused]] const bool fold = OUT32 && p.fold_out != nullptr;
+    constexpr bool fold = false;   // producers with fold_out take the split-residual epilogue above
     const int npass = (EPI == EPI_BF16_GELU && p.dual_rows > 0) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass)
 #pragma unroll

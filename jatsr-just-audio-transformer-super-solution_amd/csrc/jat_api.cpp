@@ -27,7 +27,7 @@ int jat_fail(int code, const char* fmt, ...) {
 
 // workspace carve-up for a forward over `B` batch rows of `ntok` tokens
 struct Workspace {
-  bf16_t *a_patch, *h_patch, *xn, *q, *k, *vt, *ao, *hm, *t_silu;
+  bf16_t *a_patch, *h_patch, *xn, *xlo, *q, *k, *vt, *ao, *hm, *t_silu;
   float *x, *mod, *e_sin, *t_h, *t_emb, *part;
   float* kpart;   // split-K partials of the fc2 GEMM when M is too small to fill the chip (nullptr for large M)
   int npad;
@@ -52,6 +52,7 @@ static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
   w.h_patch = (bf16_t*)take(M * m->bott * 2);
   w.x = (float*)take(M * m->D * 4);
   w.xn = (bf16_t*)take(M * m->D * 2);
+  w.xlo = (bf16_t*)take(M * m->D * 2);   // lo plane of the split residual stream (sampler with folded norms; hi = xn)
   w.q = (bf16_t*)take(M * m->D * 2);
   w.k = (bf16_t*)take(M * m->kvD * 2);
   w.vt_bytes = (size_t)B * m->Hkv * HEAD_DIM * w.npad * 2;
@@ -321,8 +322,8 @@ static int pick_variant(int M, int N, int nbatch = 1) {
   struct Cand { int id, bm, bn, slots; double f; };
   // 31-35: quadrant ping-pong (PIPE 8), one 8-wave block per CU; calibrated on profiles/r02/gemm_variants_*.log
   static const Cand cands[] = {
-      {20, 128, 128, 512, 0.80}, {18, 128, 160, 512, 0.95}, {25, 256, 160, 256, 1.00},
-      {26, 256, 128, 256, 0.90}, {21, 256, 256, 256, 1.00}, {27, 64, 160, 512, 0.60},
+      {20, 128, 128, 512, 0.95}, {18, 128, 160, 512, 0.95}, {25, 256, 160, 256, 1.00},
+      {26, 256, 128, 256, 0.90}, {21, 256, 256, 256, 1.00}, {27, 64, 160, 512, 0.60}, {28, 64, 128, 512, 0.62},
       {31, 224, 320, 256, 1.12}, {32, 256, 160, 256, 1.01}, {33, 256, 256, 256, 1.06},
       {35, 224, 256, 256, 1.06},
   };
@@ -400,7 +401,7 @@ static int resid_split(const jat_model* m, const Workspace& w, int site, int M, 
   int bm, bn;
   const int v = pick_variant(M, m->D);
   gemm_variant_tile(v, &bm, &bn);
-  const int tiles = ((M + bm - 1) / bm) * (m->D / bn), slots = (v == 18 || v == 20 || v == 27) ? 512 : 256;
+  const int tiles = ((M + bm - 1) / bm) * (m->D / bn), slots = (v == 18 || v == 20 || v == 27 || v == 28) ? 512 : 256;
   int split = slots / tiles < kSplitMax ? slots / tiles : kSplitMax;
   while (split > 1 && ((K / 64) % split != 0 || K / split < 256)) --split;   // >= 4 K-tiles per slice
   return split > 1 ? split : 1;
@@ -443,7 +444,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
-    if (f) { e.fold_out = w.xn; e.fold_part = w.part; }
+    if (f) { e.fold_out = w.xn; e.fold_lo = w.xlo; e.fold_part = w.part; }
     const int split = resid_split(m, w, G_OUT, M, D, f != nullptr);
     if (split > 1) {
       GemmArgs p{};
@@ -464,7 +465,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = L.b2; e.gate = mod_l + 5 * D; e.gate_bstride = bstride; e.ntok = ntok;
-    if (f) { e.fold_out = w.xn; e.fold_part = w.part; }   // feeds the next layer's norm1, or the final norm
+    if (f) { e.fold_out = w.xn; e.fold_lo = w.xlo; e.fold_part = w.part; }   // feeds the next layer's norm1, or the final norm
     const int split = resid_split(m, w, G_FC2, M, m->mlp, f != nullptr);
     if (split > 1) {
       GemmArgs p{};
@@ -513,7 +514,7 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = m->pe_b2; e.ntok = ntok;
-    if (f) { e.fold_out = w.xn; e.fold_part = w.part; }
+    if (f) { e.fold_out = w.xn; e.fold_lo = w.xlo; e.fold_part = w.part; }
     JCHK(gemm(m, G_OTHER, w.h_patch, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, e, s));
   }
   for (int l = 0; l < m->depth; ++l) JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s, f));

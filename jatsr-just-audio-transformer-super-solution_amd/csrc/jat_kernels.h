@@ -44,10 +44,12 @@ struct GemmArgs {
   // RMSNorm commutes with the matmul, and in the sampler every row shares the modulation (one t per step), so
   //   (x * rstd * w * (1 + scale) + shift) @ W^T  =  rstd[m] * (bf16(x) @ W'^T) + (shift @ W^T),   W' = W diag(w (1 + scale))
   // with W' and shift @ W^T precomputed per (step, layer) at sampler creation (jat_api.cpp FoldTable).
-  // producer (EPI_RESID / EPI_F32): besides x, emit fold_out[m][n] = bf16(x_new) and the row partial sums of x_new^2
-  //   of this wave's column tile into fold_part[m][nw0 / wave_tile_n]  (plain stores, fixed order);
+  // producer (EPI_RESID / EPI_F32): the residual stream is kept as two bf16 planes x = hi + lo (fold_out / fold_lo, ldo
+  //   elements per row; `out` is not touched): read-modify-write them and emit the row partial sums of x_new^2 of this
+  //   wave's column tile into fold_part[m][nw0 / wave_tile_n]  (plain stores, fixed order);
   // consumer (any epilogue): scale the accumulator row m by rsqrt(sum_j rs_part[m][j] / K + 1e-6) before the bias.
-  bf16_t* fold_out;
+  bf16_t* fold_out;   // hi plane of the split residual stream (bf16(x)): also the next GEMM's A operand
+  bf16_t* fold_lo;    // lo plane: bf16(x - hi)
   float* fold_part;
   int fold_np;
   const float* rs_part;
