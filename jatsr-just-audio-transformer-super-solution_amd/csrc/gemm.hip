@@ -39,20 +39,35 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   r.y = (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16);
   return r;
 }
-// GELU (erf form, nn.GELU() default: jat_audiosr_v3.py:223,268) as x * sigmoid(x * P(x^2)), P a cubic in x^2 fitted to
-// logit(Phi(x)) on |x| <= 7 (minimax on the absolute error; outside, x is clamped inside P only, where sigmoid is 0 or 1
-// to 1e-10).  |gelu_fast - gelu| <= 9.5e-5 for every x (tests/test_host_cpu.py checks the same expression in numpy
-// against scipy's erf), i.e. <= 1/20 of the bf16 ulp the result is rounded to at |gelu| >= 0.25.  8 VALU issues (two
-// transcendental) instead of 20 for Abramowitz-Stegun 7.1.26: the epilogue of the fc1 GEMM is VALU-bound, not store-
-// bound (140 values per lane per 224 x 320 tile).
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
-  const float x2 = xc * xc;
-  float p = fmaf(x2, 7.21813398e-06f, 9.30041738e-04f);     // coefficients pre-multiplied by -log2(e)
-  p = fmaf(p, x2, -1.06125564e-01f);
-  p = fmaf(p, x2, -2.30169559e+00f);
-  const float e = __builtin_amdgcn_exp2f(p * xc);           // exp(-x P(x^2))
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
+// GELU (erf form, nn.GELU() default: jat_audiosr_v3.py:223,268) as x * Phi(x) with Phi(x) - 1/2 = x * Q(t), Q a degree-8
+// polynomial in t = 2 x^2 / 4.5^2 - 1 (weighted minimax fit of (Phi(x) - 1/2) / x on |x| <= 4.5; outside, x is clamped inside
+// Phi only: Phi(-4.5) = 3.4e-6).  |gelu_fast - gelu| <= 3.4e-5 for |x| <= 8 in fp32 (tests/test_host_cpu.py evaluates the
+// same expression in numpy against scipy's erf), i.e. 1/60 of the bf16 ulp the result is rounded to at |gelu| ~ 1.
+// No transcendental and every operation is a multiply-add: two elements per instruction (v_pk_fma_f32) — 7 VALU issues
+// per element instead of 20 for Abramowitz-Stegun 7.1.26 + exp + rcp.  The fc1 epilogue is VALU-bound (140 values per
+// lane per 224 x 320 tile): measured 24.6 us -> see profiles/r02/epilogue_cost.log.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 xc = f32x2{__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
+#define JAT_C2(v) f32x2{v, v}
+  const f32x2 t = __builtin_elementwise_fma(xc * xc, JAT_C2(0.098765432f), JAT_C2(-1.0f));
+  f32x2 q = JAT_C2(0.0033544f);
+  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.00932879f));
+  q = __builtin_elementwise_fma(q, t, JAT_C2(0.01220736f));
+  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.01674371f));
+  q = __builtin_elementwise_fma(q, t, JAT_C2(0.02762998f));
+  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.04055589f));
+  q = __builtin_elementwise_fma(q, t, JAT_C2(0.05481848f));
+  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.07717195f));
+  q = __builtin_elementwise_fma(q, t, JAT_C2(0.15690212f));
+  const f32x2 phi = __builtin_elementwise_fma(xc, q, JAT_C2(0.5f));
+#undef JAT_C2
+  return x * phi;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
+__device__ __forceinline__ uint2 gelu_pack4(float a, float b, float c, float d) {
+  const f32x2 g0 = gelu_erf2(f32x2{a, b}), g1 = gelu_erf2(f32x2{c, d});
+  return pack4(g0[0], g0[1], g1[0], g1[1]);
 }
 
 // consumer side of the norm folding: 1/rms of row m of the A operand from the producer's partial sums (fixed order)
@@ -874,7 +889,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
           if constexpr (OUT32) {
             *(float4*)dst = float4{v[0], v[1], v[2], v[3]};
           } else if constexpr (EPI == EPI_BF16_GELU) {
-            *(uint2*)dst = pack4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+            *(uint2*)dst = gelu_pack4(v[0], v[1], v[2], v[3]);
           } else {
             *(uint2*)dst = pack4(v[0], v[1], v[2], v[3]);
           }
@@ -1045,6 +1060,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
     constexpr int SQ = 0, SK = 5 * 16384, SV = SK + 16384;
     static_assert(SV + 16384 <= 2 * STAGE, "operand images do not fit the staging buffers");
     __builtin_amdgcn_s_barrier();
+    if (p.dbg & 64) return;    // timing aid: K loop only
     float2 invf[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1083,29 +1099,45 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (p.dbg & 32) return;    // timing aid: no attention phase
     const int q = wave * 16 + frow;                // this lane's query row (B-operand column)
-    const int G = 5;
+    constexpr int G = 5;
     const int hbase = (n0 / 448) * G;
+    // The five query heads of the group are processed TOGETHER, phase by phase, instead of one head after the other:
+    // 80 independent QK^T MFMAs (each K fragment read from LDS once and used by all five heads), then five softmaxes whose
+    // exp2 / shuffles overlap, then 80 independent PV MFMAs (each V fragment read once).  One head at a time the phase was
+    // a chain of dependent LDS-read -> MFMA -> VALU steps on two waves per SIMD: 13.9 us per launch for 2.4 us of MFMA
+    // work (profiles/r02/fused_attention_phase.log).  Per-element arithmetic and accumulation order are unchanged.
+    bf16x8 qf[G][2];
+#pragma unroll
     for (int h = 0; h < G; ++h) {
-      bf16x8 qf[2];
-      qf[0] = *(const bf16x8*)(smem + SQ + h * 16384 + q * 128 + (((0 + fg) ^ (q & 7)) << 4));
-      qf[1] = *(const bf16x8*)(smem + SQ + h * 16384 + q * 128 + (((4 + fg) ^ (q & 7)) << 4));
-      f32x4 st[8];
+      qf[h][0] = *(const bf16x8*)(smem + SQ + h * 16384 + q * 128 + (((0 + fg) ^ (q & 7)) << 4));
+      qf[h][1] = *(const bf16x8*)(smem + SQ + h * 16384 + q * 128 + (((4 + fg) ^ (q & 7)) << 4));
+    }
+    f32x4 st[G][8];
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < G; ++h)
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-        const int r = 32 * (kt >> 1) + 8 * (frow >> 2) + (frow & 3) + 4 * (kt & 1);
-        const int ks = (r & 3) | (((r >> 3) & 1) << 2);
+      for (int kt = 0; kt < 8; ++kt) st[h][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 kf = *(const bf16x8*)(smem + SK + r * 128 + (((s2 * 4 + fg) ^ ks) << 4));
-          st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s2], st[kt], 0, 0, 0);
-        }
+    for (int kt = 0; kt < 8; ++kt) {
+      const int r = 32 * (kt >> 1) + 8 * (frow >> 2) + (frow & 3) + 4 * (kt & 1);
+      const int ks = (r & 3) | (((r >> 3) & 1) << 2);
+      const bf16x8 kf0 = *(const bf16x8*)(smem + SK + r * 128 + (((0 + fg) ^ ks) << 4));
+      const bf16x8 kf1 = *(const bf16x8*)(smem + SK + r * 128 + (((4 + fg) ^ ks) << 4));
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        st[h][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[h][0], st[h][kt], 0, 0, 0);
+        st[h][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[h][1], st[h][kt], 0, 0, 0);
       }
+    }
+    float inv[G];
+    bf16x8 pf[G][4];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
       float mx = -1e30f;
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
+      for (int kt = 0; kt < 8; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(st[h][kt][0], st[h][kt][1]), fmaxf(st[h][kt][2], st[h][kt][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float nb = -mx * p.attn_scale_log2e;
@@ -1114,39 +1146,45 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
       for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][e], p.attn_scale_log2e, nb));
-          st[kt][e] = pv;
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[h][kt][e], p.attn_scale_log2e, nb));
+          st[h][kt][e] = pv;
           sum += pv;
         }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      const float inv = 1.0f / sum;
-      bf16x8 pf[4];
+      inv[h] = 1.0f / sum;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         bf16x8 f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          f[e] = (__bf16)st[2 * kk][e];
-          f[4 + e] = (__bf16)st[2 * kk + 1][e];
+          f[e] = (__bf16)st[h][2 * kk][e];
+          f[4 + e] = (__bf16)st[h][2 * kk + 1][e];
         }
-        pf[kk] = f;
+        pf[h][kk] = f;
       }
-      f32x4 o[4];
+    }
+    f32x4 o[G][4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < G; ++h)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int dt = 0; dt < 4; ++dt) o[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const int d = dt * 16 + frow, ch = kk * 4 + fg;
-          const bf16x8 vf = *(const bf16x8*)(smem + SV + d * 256 + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk], o[dt], 0, 0, 0);
-        }
-      if (m0 + q < p.M) {
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + frow, ch = kk * 4 + fg;
+        const bf16x8 vf = *(const bf16x8*)(smem + SV + d * 256 + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
+#pragma unroll
+        for (int h = 0; h < G; ++h) o[h][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[h][kk], o[h][dt], 0, 0, 0);
+      }
+    if (m0 + q < p.M) {
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
         bf16_t* op = (bf16_t*)p.out + (int64_t)(m0 + q) * p.ldo + (hbase + h) * 64 + fg * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *(uint2*)(op + dt * 16) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        for (int dt = 0; dt < 4; ++dt)
+          *(uint2*)(op + dt * 16) = pack4(o[h][dt][0] * inv[h], o[h][dt][1] * inv[h], o[h][dt][2] * inv[h], o[h][dt][3] * inv[h]);
       }
     }
     return;
@@ -1198,8 +1236,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
         } else if constexpr (EPI == EPI_BF16) {
           *(uint2*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
         } else if constexpr (EPI == EPI_BF16_GELU) {
-          *(uint2*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) =
-              pack4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+          *(uint2*)((bf16_t*)p.out + (int64_t)m * p.ldo + n) = gelu_pack4(v[0], v[1], v[2], v[3]);
         } else if constexpr (EPI == EPI_RESID) {
           const float4 g = *(const float4*)(p.gate + (int64_t)b * p.gate_bstride + n);
           float4* xp = (float4*)((float*)p.out + (int64_t)m * p.ldo + n);

@@ -426,6 +426,8 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     a.out = w.ao; a.ldo = D; a.ntok = ntok; a.rope_inv_freq = m->rope_invf;
     a.attn_scale_log2e = 0.125f * 1.4426950408889634f;
     if (f) { a.rs_part = w.part; a.rs_np = m->last_fold_np; a.bias = f->bq_g + (int64_t)l * Nqkv; }
+    static const int dbg_env = getenv("JAT_GEMM_DBG") ? atoi(getenv("JAT_GEMM_DBG")) : 0;  // profiling aid (read once)
+    a.dbg = dbg_env;
     KCHK(launch_qkv_attn(a, s));
   } else {
     GemmArgs e{};

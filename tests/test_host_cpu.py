@@ -140,22 +140,27 @@ def test_chunk_plan_and_shard_range():
     assert shard_range(2, 4, 3) == (2, 2)
 
 
-def test_fast_gelu_expression_is_within_a_twentieth_of_a_bf16_ulp():
-    """csrc/gemm.hip `gelu_erf` evaluates nn.GELU() (erf form, jat_audiosr_v3.py:223,268) as x * sigmoid(x * P(x^2)) with a
-    cubic P fitted to logit(Phi(x)); the same fp32 expression in numpy against scipy's erf: |error| <= 1e-4 for every x
-    (the result is then rounded to bf16: half an ulp is 2e-3 at |gelu| ~ 1), monotone clamp outside |x| <= 7."""
+def test_fast_gelu_expression_is_far_below_a_bf16_ulp():
+    """csrc/gemm.hip `gelu_erf2` evaluates nn.GELU() (erf form, jat_audiosr_v3.py:223,268) as x * (1/2 + xc * Q(t)),
+    t = 2 xc^2 / 4.5^2 - 1, xc = clamp(x, +-4.5), Q of degree 8 (no transcendental, packed fp32 multiply-adds); the same fp32
+    expression in numpy against scipy's erf: |error| <= 4e-5 for |x| <= 8 (the result is then rounded to bf16: half an ulp
+    is 2e-3 at |gelu| ~ 1); beyond the clamp the error is relative: <= 1.2e-5 |x| on either side."""
     import numpy as np
     from scipy.special import erf
-    x = np.linspace(-30, 30, 3_000_001).astype(np.float32)
-    xc = np.clip(x, -7, 7).astype(np.float32)
-    x2 = (xc * xc).astype(np.float32)
-    p = (x2 * np.float32(7.21813398e-06) + np.float32(9.30041738e-04)).astype(np.float32)
-    p = (p * x2 + np.float32(-1.06125564e-01)).astype(np.float32)
-    p = (p * x2 + np.float32(-2.30169559e+00)).astype(np.float32)
-    with np.errstate(over="ignore"):
-        e = np.exp2((p * xc).astype(np.float32)).astype(np.float32)
-    y = (x / (np.float32(1) + e)).astype(np.float32)
+    m = np.array([0.15690212, -0.07717195, 0.05481848, -0.04055589, 0.02762998, -0.01674371, 0.01220736, -0.00932879,
+                  0.0033544], np.float32)
+
+    def gelu_fast(x):
+        x = x.astype(np.float32)
+        xc = np.clip(x, -4.5, 4.5).astype(np.float32)
+        t = (xc * xc * np.float32(0.098765432) - np.float32(1)).astype(np.float32)
+        q = np.full_like(t, m[-1])
+        for k in range(len(m) - 2, -1, -1):
+            q = (q * t + m[k]).astype(np.float32)
+        return (x * (np.float32(0.5) + xc * q).astype(np.float32)).astype(np.float32)
+    x = np.linspace(-8, 8, 1_600_001).astype(np.float32)
     ref = x.astype(np.float64) * 0.5 * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
-    assert np.abs(y - ref).max() < 1e-4
-    big = np.abs(x) > 7
-    assert np.abs(y[big] - ref[big]).max() < 1e-6      # the clamp: gelu(x) = x or 0 there
+    assert np.abs(gelu_fast(x) - ref).max() < 4e-5
+    big = np.array([10.0, 100.0, 1e4], np.float32)
+    assert np.all(np.abs(gelu_fast(big) / big - 1) < 1.2e-5)
+    assert np.all(np.abs(gelu_fast(-big)) < 1.2e-5 * big)
