@@ -191,6 +191,7 @@ def main():
         from jatsr_amd.train import Trainer
         del sampler
         Tt = args.train_T
+        # JAT_OPERAND_DTYPE=fp16 python bench.py --mode train: the v3mod2 trainer's fp16 autocast + dynamic loss scale
         trainer = Trainer(model, batch_size=B, frames=Tt, seed=1 + rank, latent_loss_weight=args.latent_loss)
         hr_t = torch.from_numpy(recipe.gaussian("train_hr", (B, C_lat, Tt), 300 + rank)).to(dev)
         lr_t = torch.from_numpy(recipe.gaussian("train_lr", (B, C_lat, Tt), 400 + rank)).to(dev)
@@ -214,7 +215,7 @@ def main():
                 "metric": "DiT training latent-frames/sec (B=28/GPU, C=1024, T=%d)" % Tt,
                 "value": world * B * Tt * args.steps / elapsed, "unit": "latent-frames/s", "n_gpus": world,
                 "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": L.operand_dtype(), "data": "synthetic",
                 "config": {"workload": f"{args.config} DDP training step (MSE + {args.latent_loss} x latent perceptual loss, "
                                        f"dropout 0.1, clip 1.0, AdamW), B={B}/GPU T={Tt}, flat-buffer gradient all-reduce "
                                        "over RCCL overlapped with the backward", "B_per_gpu": B, "T": Tt,
@@ -252,7 +253,7 @@ def main():
         "metric": "DiT latent-frames/sec (B=28,C=1024,T=512, 50-step CFG)",
         "value": value, "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": L.operand_dtype(), "data": "synthetic",
         "config": {"workload": f"{args.config} DiT {args.num_steps}-step CFG={args.cfg_scale} flow-matching sampling, "
                                f"{'hipGraph' if use_graph else 'eager'}, "
                                + (f"B={B}/GPU" if args.scaling == "weak" else f"one batch of B={args.B} sharded "

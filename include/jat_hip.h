@@ -60,6 +60,9 @@ typedef struct jat_tensor_ref {
 
 const char* jat_last_error(void);
 int jat_version(void);
+/* Operand dtype this library was built for: 0 = bf16 (libjat_hip.so: the sampler and the V3-class trainers' autocast,
+ * train_ddp_v3m2.py:545), 1 = fp16 (libjat_hip_fp16.so: torch.amp.autocast('cuda') of train_ddp_v3mod2.py:854). */
+int jat_operand_dtype(void);
 
 /* ---- model: JaT_AudioSR_V3 / _V2 (jat_audiosr_v3.py:311-471) ------------------------------------ */
 int jat_model_create(const jat_config* cfg, jat_model** out);

@@ -9,7 +9,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("JAT_LIB_PATH") or os.path.join(_HERE, "csrc", "libjat_hip.so")   # override: A/B two builds
+# JAT_OPERAND_DTYPE=fp16 selects the fp16-operand build of the same kernels for the whole process (the v3mod2 trainer's
+# autocast dtype, train_ddp_v3mod2.py:854); JAT_LIB_PATH overrides everything (A/B of two builds)
+OPERAND_DTYPE = os.environ.get("JAT_OPERAND_DTYPE", "bf16").lower()
+if OPERAND_DTYPE not in ("bf16", "fp16", "float16", "bfloat16"):
+    raise ValueError(f"JAT_OPERAND_DTYPE must be bf16 or fp16, got {OPERAND_DTYPE!r}")
+OPERAND_DTYPE = "fp16" if OPERAND_DTYPE in ("fp16", "float16") else "bf16"
+LIB_PATH = os.environ.get("JAT_LIB_PATH") or os.path.join(
+    _HERE, "csrc", "libjat_hip_fp16.so" if OPERAND_DTYPE == "fp16" else "libjat_hip.so")
 
 JAT_OK, JAT_E_INVALID, JAT_E_HIP, JAT_E_STATE, JAT_E_SEQLEN = 0, -1, -2, -3, -4
 NORM_RMS_W, NORM_LN_NOAFFINE = 0, 1
@@ -30,6 +37,7 @@ _VP, _I32, _I64, _F32, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 SIGNATURES = {
     "jat_last_error": (C.c_char_p, []),
     "jat_version": (C.c_int, []),
+    "jat_operand_dtype": (C.c_int, []),
     "jat_model_create": (C.c_int, [C.POINTER(JatConfig), C.POINTER(_VP)]),
     "jat_model_destroy": (None, [_VP]),
     "jat_model_load_weights": (C.c_int, [_VP, C.POINTER(JatTensorRef), _I32, _VP]),
@@ -88,6 +96,11 @@ def lib():
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+def operand_dtype() -> str:
+    """'bf16' or 'fp16': what the loaded library rounds GEMM / attention operands to."""
+    return "fp16" if lib().jat_operand_dtype() == 1 else "bf16"
 
 
 def check(rc: int):

@@ -17,16 +17,14 @@
 //     row bits its permuted read order exercises) — conflict-free ds_read_b128, cdna_hip_programming.md T2.
 // Softmax statistics, the running output and the 1/l normalisation are fp32; P is rounded to bf16 for PV.
 #include "jat_kernels.h"
+#include "jat_dtype.h"
 #include <cstdlib>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef jat_opx8 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__device__ __forceinline__ unsigned short f2bf_a(float f) {
-  __bf16 h = (__bf16)f;
-  return __builtin_bit_cast(unsigned short, h);
-}
+__device__ __forceinline__ unsigned short f2bf_a(float f) { return jat_f2op(f); }
 
 // K-tile chunk swizzle: the permuted row order {0-3, 8-11, 16-19, 24-27}(+4) only exercises bits 0,1,3 of the
 // row, so XOR with those (simulated conflict-free for ds_read_b128; `row & 7` would be 2-way here).
@@ -119,7 +117,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
         const bf16x8 kf = *(const bf16x8*)(sK + r * 128 + (((s * 4 + fg) ^ kswz(r)) << 4));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], st[qt][kt], 0, 0, 0);
+          st[qt][kt] = JAT_MFMA_16x16x32(kf, qf[qt][s], st[qt][kt], 0, 0, 0);
       }
     }
 
@@ -173,8 +171,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
         bf16x8 f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          f[r] = (__bf16)st[qt][2 * kk][r];
-          f[4 + r] = (__bf16)st[qt][2 * kk + 1][r];
+          f[r] = (jat_op_t)st[qt][2 * kk][r];
+          f[4 + r] = (jat_op_t)st[qt][2 * kk + 1][r];
         }
         pf[qt][kk] = f;
       }
@@ -190,7 +188,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
         const bf16x8 vf = *(const bf16x8*)(sV + d * (KVB * 2) + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], o[qt][dt], 0, 0, 0);
+          o[qt][dt] = JAT_MFMA_16x16x32(vf, pf[qt][kk], o[qt][dt], 0, 0, 0);
       }
   }
 
@@ -278,7 +276,7 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
         const bf16x8 kf = *(const bf16x8*)(sK + r * 128 + (((s * 4 + fg) ^ kswz(r)) << 4));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], st[qt][kt], 0, 0, 0);
+          st[qt][kt] = JAT_MFMA_16x16x32(kf, qf[qt][s], st[qt][kt], 0, 0, 0);
       }
     }
     bf16x8 pf[QT][NKK];
@@ -316,8 +314,8 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
         bf16x8 f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          f[r] = (__bf16)st[qt][2 * kk][r];
-          f[4 + r] = (__bf16)st[qt][2 * kk + 1][r];
+          f[r] = (jat_op_t)st[qt][2 * kk][r];
+          f[4 + r] = (jat_op_t)st[qt][2 * kk + 1][r];
         }
         pf[qt][kk] = f;
       }
@@ -335,7 +333,7 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
         const bf16x8 vf = *(const bf16x8*)(sV + d * 256 + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-          o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], o[qt][dt], 0, 0, 0);
+          o[qt][dt] = JAT_MFMA_16x16x32(vf, pf[qt][kk], o[qt][dt], 0, 0, 0);
       }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {

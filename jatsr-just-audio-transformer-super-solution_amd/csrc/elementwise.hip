@@ -2,12 +2,10 @@
 // All of them stream 16 B per lane (cdna_hip_programming.md Guideline 13) and reduce with 64-wide
 // wavefront shuffles; none is GEMM-shaped.
 #include "jat_kernels.h"
+#include "jat_dtype.h"
 #include <cstdlib>
 
-__device__ __forceinline__ unsigned short f2bf_e(float f) {
-  __bf16 h = (__bf16)f;
-  return __builtin_bit_cast(unsigned short, h);
-}
+__device__ __forceinline__ unsigned short f2bf_e(float f) { return jat_f2op(f); }
 __device__ __forceinline__ uint2 pack4_e(float a, float b, float c, float d) {
   uint2 r;
   r.x = (unsigned)f2bf_e(a) | ((unsigned)f2bf_e(b) << 16);

@@ -24,15 +24,13 @@
 //             phase B: MFMA(F1)                    ||  ds_read F0 <- tile t+1, k-step 0
 // M may be ragged (rows clamped on load, masked on store); N % BN == 0 and K % 64 == 0 are required.
 #include "jat_kernels.h"
+#include "jat_dtype.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef jat_opx8 bf16x8;   // 8 operand elements (bf16, or fp16 in the -DJAT_FP16 build): one MFMA fragment
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
-  return __builtin_bit_cast(unsigned short, h);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return jat_f2op(f); }
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   uint2 r;
   r.x = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
@@ -68,6 +66,13 @@ __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x
 __device__ __forceinline__ uint2 gelu_pack4(float a, float b, float c, float d) {
   const f32x2 g0 = gelu_erf2(f32x2{a, b}), g1 = gelu_erf2(f32x2{c, d});
   return pack4(g0[0], g0[1], g1[0], g1[1]);
+}
+
+// RoPE rotation of one pair (a, b) by the angle with cosine c and sine s, multiply-add contraction spelled out: left to
+// -ffp-contract=fast the compiler may fuse a*c - b*s either way, differently at each call site, and the fused and the separate
+// QKV paths would then differ in the last fp32 bit (visible after rounding to fp16; caught by the bit-identity test).
+__device__ __forceinline__ float2 rope_rot(float a, float b, float c, float s) {
+  return float2{__builtin_fmaf(a, c, -(b * s)), __builtin_fmaf(b, c, a * s)};
 }
 
 // consumer side of the norm folding: 1/rms of row m of the A operand from the producer's partial sums (fixed order)
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = JAT_MFMA_16x16x32(wf[j], af[i], acc[i][j], 0, 0, 0);
   };
 
   // norm folding, consumer side: 1/rms of this lane's TM rows, loaded before the K loop so the latency is hidden
@@ -574,7 +579,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
   if (!abl_mma) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
   _Pragma("unroll") for (int i = 0; i < (IC); ++i)                                                              \
   _Pragma("unroll") for (int j = 0; j < (JC); ++j)                                                              \
-    acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[(I0) + i][(J0) + j], 0, 0, 0);
+    acc[(I0) + i][(J0) + j] = JAT_MFMA_16x16x32(fb[ks][j], fa[ks][i], acc[(I0) + i][(J0) + j], 0, 0, 0);
 #define JAT_LOAD_END()                              \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0);                \
@@ -765,7 +770,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
-      auto up = [](unsigned u, float& a, float& b) { a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u); };
+      auto up = [](unsigned u, float& a, float& b) { a = jat_lo2f(u); b = jat_hi2f(u); };
 #pragma unroll
       for (int ig = 0; ig < (TM + 1) / 2; ++ig) {
         const int grows = (2 * ig + 1 < TM) ? 32 : 16;
@@ -818,7 +823,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
           for (int e = 0; e < 4; ++e) {
             const unsigned short ha = f2bf(x[2 * e]), hb = f2bf(x[2 * e + 1]);
             ho[e] = (unsigned)ha | ((unsigned)hb << 16);
-            const float ra = x[2 * e] - __uint_as_float((unsigned)ha << 16), rb = x[2 * e + 1] - __uint_as_float((unsigned)hb << 16);
+            const float ra = x[2 * e] - jat_op2f(ha), rb = x[2 * e + 1] - jat_op2f(hb);
             lw2[e] = (unsigned)f2bf(ra) | ((unsigned)f2bf(rb) << 16);
             sq += x[2 * e] * x[2 * e] + x[2 * e + 1] * x[2 * e + 1];
           }
@@ -1000,9 +1005,8 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
             const float r1 = __builtin_amdgcn_fractf((float)pos * invf[j].y * 0.15915494309189535f);
             const float2 c = float2{__builtin_amdgcn_cosf(r0), __builtin_amdgcn_cosf(r1)};
             const float2 s = float2{__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1)};
-            *(uint2*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 2) =
-                pack4(v[0] * c.x - v[1] * s.x, v[1] * c.x + v[0] * s.x, v[2] * c.y - v[3] * s.y,
-                      v[3] * c.y + v[2] * s.y);
+            const float2 r01 = rope_rot(v[0], v[1], c.x, s.x), r23 = rope_rot(v[2], v[3], c.y, s.y);
+            *(uint2*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 2) = pack4(r01.x, r01.y, r23.x, r23.y);
           } else if (vfast) {  // v tile: plain bf16 into the slab, transposed out below
             *(uint2*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 2) = pack4(v[0], v[1], v[2], v[3]);
           } else if (mw0 + (2 * ig + ii) * 16 + frow < p.M) {  // ragged token count: element-wise transposed store
@@ -1083,7 +1087,8 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
           const float r1 = __builtin_amdgcn_fractf((float)r * invf[j].y * 0.15915494309189535f);
           const float c0 = __builtin_amdgcn_cosf(r0), c1 = __builtin_amdgcn_cosf(r1);
           const float s0 = __builtin_amdgcn_sinf(r0), s1 = __builtin_amdgcn_sinf(r1);
-          const uint2 pk = pack4(v[0] * c0 - v[1] * s0, v[1] * c0 + v[0] * s0, v[2] * c1 - v[3] * s1, v[3] * c1 + v[2] * s1);
+          const float2 r01 = rope_rot(v[0], v[1], c0, s0), r23 = rope_rot(v[2], v[3], c1, s1);
+          const uint2 pk = pack4(r01.x, r01.y, r23.x, r23.y);
           const int colb = ((nl & 63) + fg * 4) * 2, chunk = colb >> 4, off = colb & 15;
           if (nl < 320) *(uint2*)(smem + SQ + (nl >> 6) * 16384 + r * 128 + ((chunk ^ (r & 7)) << 4) + off) = pk;
           else *(uint2*)(smem + SK + r * 128 + ((chunk ^ ((r & 3) | (((r >> 3) & 1) << 2))) << 4) + off) = pk;
@@ -1127,8 +1132,8 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
       const bf16x8 kf1 = *(const bf16x8*)(smem + SK + r * 128 + (((4 + fg) ^ ks) << 4));
 #pragma unroll
       for (int h = 0; h < G; ++h) {
-        st[h][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[h][0], st[h][kt], 0, 0, 0);
-        st[h][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[h][1], st[h][kt], 0, 0, 0);
+        st[h][kt] = JAT_MFMA_16x16x32(kf0, qf[h][0], st[h][kt], 0, 0, 0);
+        st[h][kt] = JAT_MFMA_16x16x32(kf1, qf[h][1], st[h][kt], 0, 0, 0);
       }
     }
     float inv[G];
@@ -1158,8 +1163,8 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
         bf16x8 f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          f[e] = (__bf16)st[h][2 * kk][e];
-          f[4 + e] = (__bf16)st[h][2 * kk + 1][e];
+          f[e] = (jat_op_t)st[h][2 * kk][e];
+          f[4 + e] = (jat_op_t)st[h][2 * kk + 1][e];
         }
         pf[h][kk] = f;
       }
@@ -1176,7 +1181,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
         const int d = dt * 16 + frow, ch = kk * 4 + fg;
         const bf16x8 vf = *(const bf16x8*)(smem + SV + d * 256 + (ch >> 3) * 128 + (((ch & 7) ^ (d & 7)) << 4));
 #pragma unroll
-        for (int h = 0; h < G; ++h) o[h][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[h][kk], o[h][dt], 0, 0, 0);
+        for (int h = 0; h < G; ++h) o[h][dt] = JAT_MFMA_16x16x32(vf, pf[h][kk], o[h][dt], 0, 0, 0);
       }
     if (m0 + q < p.M) {
 #pragma unroll

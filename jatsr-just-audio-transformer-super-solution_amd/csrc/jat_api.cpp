@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "jat_internal.h"
+#include "jat_dtype.h"
 
 static thread_local char g_err[512] = "";
 int jat_fail(int code, const char* fmt, ...) {
@@ -71,7 +72,8 @@ static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
 }
 
 extern "C" const char* jat_last_error(void) { return g_err; }
-extern "C" int jat_version(void) { return 1; }
+extern "C" int jat_version(void) { return 2; }
+extern "C" int jat_operand_dtype(void) { return JAT_OPERAND_DTYPE; }   // 0 bf16, 1 fp16 (jat_dtype.h)
 
 // ---------------------------------------------------------------------------------------------------------
 // model

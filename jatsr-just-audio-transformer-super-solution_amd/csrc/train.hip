@@ -4,19 +4,17 @@
 // by transpose_bf16_kernel.  Everything here is either HBM-bound row/column work or the attention backward.
 // All reductions are fixed-order (partials + a finishing kernel): no atomics, a step is bit-reproducible.
 #include "jat_kernels.h"
+#include "jat_dtype.h"
 #include "jat_rng.h"
 #include <cstdlib>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef jat_opx8 bf16x8_t;   // operand fragment: bf16, or fp16 in the -DJAT_FP16 build (jat_dtype.h)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 
-__device__ __forceinline__ unsigned short f2bf_t(float f) {
-  __bf16 h = (__bf16)f;
-  return __builtin_bit_cast(unsigned short, h);
-}
-__device__ __forceinline__ float bf2f_t(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf_t(float f) { return jat_f2op(f); }
+__device__ __forceinline__ float bf2f_t(unsigned short u) { return jat_op2f(u); }
 __device__ __forceinline__ float wave_sum_t(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -25,8 +23,8 @@ __device__ __forceinline__ float wave_sum_t(float v) {
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-    f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    f[2 * i] = jat_lo2f(v[i]);
+    f[2 * i + 1] = jat_hi2f(v[i]);
   }
 }
 __device__ __forceinline__ u32x4_t pack8(const float* f) {
@@ -211,8 +209,8 @@ __global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__
       const int64_t row = (int64_t)b * ntok + t;
       const f32x4_t d = *(const f32x4_t*)(dx + row * D + c);
       const u32x2_t yy = *(const u32x2_t*)(y + row * D + c);
-      const float y0 = __builtin_bit_cast(float, yy[0] << 16), y1 = __builtin_bit_cast(float, yy[0] & 0xffff0000u);
-      const float y2 = __builtin_bit_cast(float, yy[1] << 16), y3 = __builtin_bit_cast(float, yy[1] & 0xffff0000u);
+      const float y0 = jat_lo2f(yy[0]), y1 = jat_hi2f(yy[0]);
+      const float y2 = jat_lo2f(yy[1]), y3 = jat_hi2f(yy[1]);
       float e0 = pm, e1 = pm, e2 = pm, e3 = pm;   // d(branch)/d(gate*y) multipliers: DropPath x element dropout
       float h0 = 1.f, h1 = 1.f, h2 = 1.f, h3 = 1.f;
       if (elem.thresh) {
@@ -297,8 +295,8 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const float* __restrict__
       if (c < nch) {
         xv[c] = *(const f32x4_t*)(x + row * D + c * 256 + lane * 4);
         const u32x2_t d2 = *(const u32x2_t*)(dy + row * D + c * 256 + lane * 4);
-        dv[c][0] = __builtin_bit_cast(float, d2[0] << 16); dv[c][1] = __builtin_bit_cast(float, d2[0] & 0xffff0000u);
-        dv[c][2] = __builtin_bit_cast(float, d2[1] << 16); dv[c][3] = __builtin_bit_cast(float, d2[1] & 0xffff0000u);
+        dv[c][0] = jat_lo2f(d2[0]); dv[c][1] = jat_hi2f(d2[0]);
+        dv[c][2] = jat_lo2f(d2[1]); dv[c][3] = jat_hi2f(d2[1]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1 += xv[c][j]; s2 += xv[c][j] * xv[c][j]; }
       }
@@ -450,7 +448,7 @@ __device__ __forceinline__ void strip_mma(unsigned short (*X)[AP], int xr0, unsi
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const bf16x8_t bb = *(const bf16x8_t*)&Y[nt * 16 + fr][ks * 32 + fg * 8];
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nt], 0, 0, 0);
+      acc[nt] = JAT_MFMA_16x16x32(a, bb, acc[nt], 0, 0, 0);
     }
   }
 }
@@ -473,7 +471,7 @@ __device__ __forceinline__ void strip_mma_swzY(unsigned short (*X)[AP], int xr0,
     for (int nt = 0; nt < 4; ++nt) {
       const int r = nt * 16 + fr;
       const bf16x8_t bb = *(const bf16x8_t*)&Ysw[r][((ks * 4 + fg) ^ (r & 7)) * 8];
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nt], 0, 0, 0);
+      acc[nt] = JAT_MFMA_16x16x32(a, bb, acc[nt], 0, 0, 0);
     }
   }
 }
@@ -487,7 +485,7 @@ __device__ __forceinline__ void strip_mma_tr_swzX(unsigned short (*Xsw)[64], int
     const bf16x8_t a = *(const bf16x8_t*)&Xsw[r][((ks * 4 + fg) ^ (r & 7)) * 8];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, tr_frag(Yt, ks * 32, nt * 16, lane), acc[nt], 0, 0, 0);
+      acc[nt] = JAT_MFMA_16x16x32(a, tr_frag(Yt, ks * 32, nt * 16, lane), acc[nt], 0, 0, 0);
   }
 }
 // Operand fragment of a TRANSPOSED image: element j of lane (fg, fr) = img[k0 + 8 fg + j][c0 + fr], j = 0..7, by two
@@ -511,7 +509,7 @@ __device__ __forceinline__ void strip_mma_tr(unsigned short (*X)[AP], int xr0, u
     const bf16x8_t a = *(const bf16x8_t*)&X[xr0 + fr][ks * 32 + fg * 8];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, tr_frag(Yt, ks * 32, nt * 16, lane), acc[nt], 0, 0, 0);
+      acc[nt] = JAT_MFMA_16x16x32(a, tr_frag(Yt, ks * 32, nt * 16, lane), acc[nt], 0, 0, 0);
   }
 }
 // acc[nt] += Xt[k][xc0 + m] * Y[16 nt + n][k]      (first operand stored k-major)
@@ -523,7 +521,7 @@ __device__ __forceinline__ void strip_mma_trA(unsigned short (*Xt)[AP], int xc0,
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const bf16x8_t bb = *(const bf16x8_t*)&Y[nt * 16 + fr][ks * 32 + fg * 8];
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[nt], 0, 0, 0);
+      acc[nt] = JAT_MFMA_16x16x32(a, bb, acc[nt], 0, 0, 0);
     }
   }
 }
@@ -947,8 +945,8 @@ __global__ void __launch_bounds__(320) small_dx_kernel(const float* __restrict__
       f32x4_t w;
       if constexpr (sizeof(WT) == 2) {
         const u32x2_t ww = *(const u32x2_t*)(W + (int64_t)n * K + k);
-        w[0] = __builtin_bit_cast(float, ww[0] << 16); w[1] = __builtin_bit_cast(float, ww[0] & 0xffff0000u);
-        w[2] = __builtin_bit_cast(float, ww[1] << 16); w[3] = __builtin_bit_cast(float, ww[1] & 0xffff0000u);
+        w[0] = jat_lo2f(ww[0]); w[1] = jat_hi2f(ww[0]);
+        w[2] = jat_lo2f(ww[1]); w[3] = jat_hi2f(ww[1]);
       } else {
         w = *(const f32x4_t*)(W + (int64_t)n * K + k);
       }

@@ -107,12 +107,21 @@ class Trainer:
                  warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None,
                  latent_loss_weight=0.0, freq_loss_weight=0.5, ms_loss_weight=0.5, consistency_weight=0.1,
                  low_freq_phase_ratio=0.3, strict_cutoff=0.30, soft_cutoff=0.36, overlap_grad_allreduce=True,
-                 distributed=True):
+                 distributed=True, amp_dtype=None):
         """latent_loss_weight > 0 selects the v3mod2 trainer's loss, MSE + latent perceptual loss
         (train_ddp_v3mod2.py:53-321,362-372,889-896; its TrainConfig uses 0.3 with the other defaults given here, no CFG
         dropout and condition_noise_ratio 0.05); 0 is the MSE-only loss of train_ddp_v3m2.py:585.
-        distributed=False: never issue a collective even if a process group exists (a single rank timing a local step)."""
+        distributed=False: never issue a collective even if a process group exists (a single rank timing a local step).
+        amp_dtype: "bf16" (train_ddp_v3m2.py:545) or "fp16" (`torch.amp.autocast('cuda')` of train_ddp_v3mod2.py:854, with
+        the dynamic loss scale of :745); must match the operand dtype of the loaded library, which is a process-level
+        choice (JAT_OPERAND_DTYPE=fp16 loads libjat_hip_fp16.so).  None: whatever the library is."""
         L.require_gpu()
+        have = L.operand_dtype()
+        want = {None: have, "bf16": "bf16", "bfloat16": "bf16", "fp16": "fp16", "float16": "fp16"}[amp_dtype]
+        if want != have:
+            raise L.JatError(f"amp_dtype={want} needs the {want}-operand library: start the process with "
+                             f"JAT_OPERAND_DTYPE={want} (loaded: {L.LIB_PATH}, {have})")
+        self.amp_dtype = have
         self.model = model
         self.B, self.T = int(batch_size), int(frames)
         self.base_lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps

@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 
 import jatsr_amd._lib as L  # noqa: E402
 
+# operand dtype of the loaded library: bf16, or fp16 when the process runs with JAT_OPERAND_DTYPE=fp16 (the v3mod2 trainer's
+# autocast dtype; tests/test_gpu_fp16.py re-runs this module that way).  fp16 has 3 more mantissa bits: same gates hold.
+OP = torch.float16 if L.OPERAND_DTYPE == "fp16" else OP
+
 
 def dev():
     L.require_gpu()
@@ -22,7 +26,7 @@ def dev():
 
 
 def bf16_bits(t):  # fp32 tensor -> (uint16-bits tensor as int16 view, rounded fp32 values)
-    b = t.to(torch.bfloat16)
+    b = t.to(OP)
     return b, b.float()
 
 
@@ -38,9 +42,9 @@ def gen(shape, seed, scale=1.0):
 
 def test_cast_bf16():
     x = gen((3, 1001), 1)
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(x.shape, dtype=OP, device=x.device)
     L.check(L.lib().jat_k_cast_bf16(L.ptr(x), L.ptr(out), x.numel(), L.stream_ptr()))
-    assert torch.equal(out, x.to(torch.bfloat16))
+    assert torch.equal(out, x.to(OP))
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -50,7 +54,7 @@ def test_norm_modulate(mode, D, M, ntok, shared):
     x = gen((M, D), 2, 3.0) + 0.5
     w = 1 + 0.2 * gen((D,), 3)
     mod = gen((1 if shared else B, 2 * D), 4, 0.3)
-    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(M, D, dtype=OP, device=x.device)
     shift, scale = mod[:, :D], mod[:, D:]
     L.check(L.lib().jat_k_norm_modulate(L.ptr(x), L.ptr(w), C.c_void_p(mod.data_ptr()),
                                         C.c_void_p(mod.data_ptr() + 4 * D), 0 if shared else 2 * D, L.ptr(y), M, D,
@@ -74,7 +78,7 @@ def test_norm_no_modulation():
     D, M = 1280, 37
     x = gen((M, D), 5)
     w = 1 + 0.2 * gen((D,), 6)
-    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(M, D, dtype=OP, device=x.device)
     L.check(L.lib().jat_k_norm_modulate(L.ptr(x), L.ptr(w), None, None, 0, L.ptr(y), M, D, M, 0, L.stream_ptr()))
     xd = x.double()
     ref = xd / torch.sqrt((xd * xd).mean(-1, keepdim=True) + 1e-6) * w.double()
@@ -107,7 +111,7 @@ def test_gemm(variant, M, N, K, epi):
     if epi == 0:
         out = torch.full((M, N), float("nan"), device=A.device)
     elif epi in (1, 2):
-        out = torch.zeros((M, N), dtype=torch.bfloat16, device=A.device)
+        out = torch.zeros((M, N), dtype=OP, device=A.device)
     else:
         out = gen((M, N), 32)
         x0 = out.clone()
@@ -119,7 +123,7 @@ def test_gemm(variant, M, N, K, epi):
         assert (out.double() - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
     elif epi == 1:
         assert rel(out, ref) < 3e-3
-        assert torch.equal(out, ref.float().to(torch.bfloat16)) or (out.float() - ref.float()).abs().max() <= \
+        assert torch.equal(out, ref.float().to(OP)) or (out.float() - ref.float()).abs().max() <= \
             2 ** -8 * float(ref.abs().max())
     elif epi == 2:
         g = torch.nn.functional.gelu(ref)  # erf form, fp64
@@ -148,9 +152,9 @@ def test_attention(B, N, Hq, Hkv):
     q, qf = bf16_bits(gen((B * N, Hq * 64), 40, 1.5))
     k, kf = bf16_bits(gen((B * N, Hkv * 64), 41, 1.5))
     v, vf = bf16_bits(gen((B * N, Hkv * 64), 42))
-    vt = torch.zeros(B, Hkv, 64, npad, dtype=torch.bfloat16, device=q.device)
+    vt = torch.zeros(B, Hkv, 64, npad, dtype=OP, device=q.device)
     vt[:, :, :, :N] = v.view(B, N, Hkv, 64).permute(0, 2, 3, 1)
-    o = torch.zeros(B * N, Hq * 64, dtype=torch.bfloat16, device=q.device)
+    o = torch.zeros(B * N, Hq * 64, dtype=OP, device=q.device)
     L.check(L.lib().jat_k_attention(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(o), B, N, Hq, Hkv, npad, L.stream_ptr()))
     ref = _attention_ref(qf, kf, vf, B, N, Hq, Hkv)
     # P is rounded to bf16 before PV and the output once more: ~2^-8 relative to the value scale
@@ -170,7 +174,7 @@ def test_attention_spiky_rows():
     k, kf = bf16_bits(kx)
     v, vf = bf16_bits(gen((B * N, Hkv * 64), 52))
     vt = v.view(B, N, Hkv, 64).permute(0, 2, 3, 1).contiguous()
-    o = torch.zeros(B * N, Hq * 64, dtype=torch.bfloat16, device=q.device)
+    o = torch.zeros(B * N, Hq * 64, dtype=OP, device=q.device)
     L.check(L.lib().jat_k_attention(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(o), B, N, Hq, Hkv, npad, L.stream_ptr()))
     ref = _attention_ref(qf, kf, vf, B, N, Hq, Hkv)
     assert rel(o, ref) < 6e-3

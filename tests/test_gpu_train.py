@@ -22,6 +22,8 @@ from helpers import load_golden, rel_l2  # noqa: E402
 from jatsr_amd.model import JaT_AudioSR_V2, JaT_AudioSR_V3  # noqa: E402
 from jatsr_amd.train import Trainer  # noqa: E402
 
+FP16 = L.OPERAND_DTYPE == "fp16"      # the library under test rounds operands to fp16 (JAT_OPERAND_DTYPE=fp16)
+FP16_TEST_SCALE = 4096.0
 GRAD_TOL = 3e-2        # per-tensor rel-L2 of a gradient vs the fp64 reference
 GRAD_TOL_SMALL = 8e-2  # tensors whose gradient norm is < 1e-3 of the global norm (dominated by rounding noise)
 LOSS_TOL, GNORM_TOL = 2e-3, 1e-2
@@ -51,6 +53,11 @@ def make_trainer(meta, **kw):
     m = m.to("cuda")
     tr = Trainer(m, batch_size=meta["B"], frames=meta["T"], lr=meta["lr"], weight_decay=meta["wd"],
                  grad_clip=meta["clip"], **kw)
+    if FP16 and not kw.get("use_grad_scaler", True):
+        # fp16 operands (tests/test_gpu_fp16.py): gradients of 1e-6 sit in fp16's denormal range — what the reference's
+        # GradScaler is for (train_ddp_v3mod2.py:745).  The parity tests run the step at a fixed loss scale instead of a
+        # dynamic one; every comparison below divides the (scaled) gradient buffer by `tr.scaler.scale`.
+        tr.scaler.scale = FP16_TEST_SCALE
     return m, tr
 
 
@@ -126,7 +133,7 @@ def _check_step_vs_golden(name, with_adamw):
     gn_ref = float(z["gnorm64"])
     worst, sq = ("", 0.0), 0.0
     for k in meta["names"]:
-        g = tr.grad(k).detach().cpu().numpy()
+        g = (tr.grad(k).detach() / tr.scaler.scale).cpu().numpy()
         assert np.isfinite(g).all(), k
         sq += float((g.astype(np.float64) ** 2).sum())
         ref_l2 = float(z["gl2_" + k])
@@ -171,7 +178,8 @@ def test_step_is_deterministic_and_loss_scale_invariant():
     z, meta = load_golden("train_micro_T22_pad")
     hr, lr, noise, t, mask = step_inputs(meta)
     grads = []
-    for scale in (1.0, 1.0, 1024.0):
+    base = FP16_TEST_SCALE if FP16 else 1.0
+    for scale in (base, base, base * 1024.0):
         m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
         tr.scaler.scale = scale
         z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
@@ -237,7 +245,7 @@ def test_train_step_vs_numpy_oracle(cfg_name, B, T, norm, salt):
     gn = math.sqrt(sum(float((g * g).sum()) for g in grads.values()))
     worst = 0.0
     for k, g in grads.items():
-        r = rel_l2(tr.grad(k).cpu().numpy(), g)
+        r = rel_l2((tr.grad(k) / tr.scaler.scale).cpu().numpy(), g)
         tol = GRAD_TOL if np.linalg.norm(g) >= 1e-3 * gn else GRAD_TOL_SMALL
         worst = max(worst, r / tol)
         assert r <= tol, f"{k}: {r:.3e}"
@@ -264,7 +272,7 @@ def test_dropout_and_droppath_vs_reference_golden(name):
     gn_ref = math.sqrt(sum(float(z["gl2_" + k]) ** 2 for k in meta["names"]))
     worst = ("", 0.0)
     for k in meta["names"]:
-        g = tr.grad(k).cpu().numpy()
+        g = (tr.grad(k) / tr.scaler.scale).cpu().numpy()
         ref_l2 = float(z["gl2_" + k])
         r = rel_l2(gsub(g, meta), z["g_" + k])
         tol = GRAD_TOL if ref_l2 >= 1e-3 * gn_ref else GRAD_TOL_SMALL
@@ -362,7 +370,7 @@ def test_v3mod2_step_vs_reference_golden(name):
     gn = math.sqrt(sum(float((g * g).sum()) for g in grads.values()))
     worst = ("", 0.0)
     for k in meta["names"]:
-        r = rel_l2(tr.grad(k).cpu().numpy(), grads[k])
+        r = rel_l2((tr.grad(k) / tr.scaler.scale).cpu().numpy(), grads[k])
         tol = GRAD_TOL if np.linalg.norm(grads[k]) >= 1e-3 * gn else GRAD_TOL_SMALL
         if r / tol > worst[1]:
             worst = (k, r / tol)
@@ -402,7 +410,7 @@ def test_v3mod2_step_gradients_vs_reference_autograd_conditioned(name):
     gn_ref = math.sqrt(sum(float(z["gl2_" + k]) ** 2 for k in meta["names"]))
     worst, sq = ("", 0.0), 0.0
     for k in meta["names"]:
-        g = tr.grad(k).detach().cpu().numpy()
+        g = (tr.grad(k).detach() / tr.scaler.scale).cpu().numpy()
         sq += float((g.astype(np.float64) ** 2).sum())
         ref_l2 = float(z["gl2_" + k])
         r = rel_l2(gsub(g, meta), z["g_" + k])
@@ -519,7 +527,7 @@ def test_dropout_full_width_vs_numpy_oracle():
     assert abs(float(tr._scal[0]) - loss) <= LOSS_TOL * loss
     gn = math.sqrt(sum(float((g * g).sum()) for g in grads.values()))
     for k, g in grads.items():
-        r = rel_l2(tr.grad(k).cpu().numpy(), g)
+        r = rel_l2((tr.grad(k) / tr.scaler.scale).cpu().numpy(), g)
         assert r <= (GRAD_TOL if np.linalg.norm(g) >= 1e-3 * gn else GRAD_TOL_SMALL), f"{k}: {r:.3e}"
 
 
@@ -624,3 +632,34 @@ def test_skipped_step_advances_the_schedule_counter_not_adamw():
     assert float(sd["state"][0]["step"]) == 1.0
     ck = tr.save_checkpoint("/tmp/_jat_ck_counters.pt")
     assert ck["global_step"] == 2
+
+
+def test_fp16_autocast_overflow_backs_the_scale_off_and_training_proceeds():
+    """v3mod2 trainer semantics (train_ddp_v3mod2.py:745,854,922-930): fp16 operands overflow above 65504, the GradScaler
+    skips that step and halves the scale, later steps go through.  Runs against whichever library is loaded: under bf16
+    (this process) nothing overflows at scale 2^16 and every step is taken; tests/test_gpu_fp16.py re-runs it with the
+    fp16 library, where a loss scale of 2^30 must overflow the backward's fp16 operands and be backed off."""
+    z, meta = load_golden("train_micro_mod2_T24")
+    fp16 = L.operand_dtype() == "fp16"
+    m, tr = make_trainer(dict(meta, lr=5e-5, wd=0.1, clip=1.0), use_grad_scaler=True, condition_noise_ratio=0.05,
+                         latent_loss_weight=0.3, amp_dtype="fp16" if fp16 else "bf16", seed=11)
+    assert tr.amp_dtype == ("fp16" if fp16 else "bf16")
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    C, B, T, salt = cfg["input_channels"], meta["B"], meta["T"], meta["salt"]
+    hr = cuda(recipe.gaussian("train_hr", (B, C, T), salt + 300))
+    lr = cuda(recipe.gaussian("train_lr", (B, C, T), salt + 301))
+    mean, std = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    tr.scaler.scale = 2.0 ** 30 if fp16 else 65536.0
+    taken, scales = 0, []
+    for _ in range(24):
+        st = tr.train_step(hr, lr, mean, std, mean, std)
+        scales.append(tr.scaler.scale)
+        taken = tr.opt_step
+    assert tr.global_step == 24
+    if fp16:
+        assert scales[0] < 2.0 ** 30 and taken < 24, "a 2^30 loss scale must overflow fp16 gradients at least once"
+        assert taken >= 8 and np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"])   # backed off until steps go through
+    else:
+        assert taken == 24 and scales[-1] == 65536.0
+    with pytest.raises(L.JatError):
+        Trainer(type(m)(**cfg), batch_size=B, frames=T, amp_dtype="bf16" if fp16 else "fp16")
