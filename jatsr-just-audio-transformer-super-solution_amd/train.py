@@ -98,6 +98,18 @@ def allreduce_mean_(flat, group=None):
     return world
 
 
+def reduce_validation_sums(acc, group=None):
+    """ONE all-reduce of the 8-slot vector [sum loss, steps, mse, freq, ms, consistency, latent, -] over the ranks, in place:
+    what train_ddp_v3mod2.py:1087-1096 does with seven 1-float all-reduces.  Returns (avg_loss, {metric: avg}) of the
+    GLOBAL sums / steps (every rank gets the same numbers)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    steps = max(float(acc[1]), 1.0)
+    metrics = dict(zip(("mse_loss", "freq_loss", "ms_loss", "consistency_loss", "total_latent_loss"), (acc[2:7] / steps).tolist()))
+    return float(acc[0]) / steps, metrics
+
+
 class Trainer:
     """One rank of the reference training loop.  Hyper-parameter names and defaults are TrainConfig's
     (train_ddp_v3m2.py:55-101)."""
@@ -386,16 +398,16 @@ class Trainer:
             o = out6.double()
             acc[0] += o[0]; acc[1] += 1; acc[2:7] += o[1:6]
             losses.append(float(o[0]))
-        import torch.distributed as dist
-        if self._dist_on() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
-        steps = max(float(acc[1]), 1.0)
-        avg = float(acc[0]) / steps
-        std = float(torch.tensor(losses).std()) if len(losses) > 1 else 0.0
-        metrics = {}
-        if ll["latent_weight"] != 0.0:
+        if self._dist_on():
+            avg, metrics = reduce_validation_sums(acc, self.group)
+        else:
+            steps = max(float(acc[1]), 1.0)
+            avg = float(acc[0]) / steps
             metrics = dict(zip(("mse_loss", "freq_loss", "ms_loss", "consistency_loss", "total_latent_loss"),
                                (acc[2:7] / steps).tolist()))
+        std = float(torch.tensor(losses).std()) if len(losses) > 1 else 0.0
+        if ll["latent_weight"] == 0.0:
+            metrics = {}
         return avg, std, metrics
 
     # -- checkpoint egress / ingest in the reference's layout (train_ddp_v3m2.py:747-770, 443-500) ----------------------

@@ -209,6 +209,43 @@ def test_gradient_exchange_reduce_scatter_all_gather_world2_gloo():
         assert got[0][mode][1] == got[1][mode][1], mode       # replicas hold identical sums
 
 
+def _val_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 0 validated 3 batches, rank 1 validated 2 (a ragged DistributedSampler split): sums, not means, travel
+    per_rank = {0: [1.0, 2.0, 3.0], 1: [10.0, 20.0]}[rank]
+    acc = torch.zeros(8, dtype=torch.float64)
+    for v in per_rank:
+        acc[0] += v; acc[1] += 1; acc[2:7] += torch.tensor([v, 2 * v, 3 * v, 4 * v, 5 * v], dtype=torch.float64)
+    avg, metrics = T.reduce_validation_sums(acc)
+    out.put((rank, avg, metrics))
+    dist.destroy_process_group()
+
+
+def test_validation_reduce_world2_gloo():
+    """The validation metrics of all ranks combine in ONE 8-float all-reduce of SUMS (train_ddp_v3mod2.py:1087-1096 issues
+    seven 1-float ones): global average = sum of all batch losses / number of batches, identical on every rank."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (a, m)) for r, a, m in (q.get(timeout=120) for _ in procs))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1]
+    avg, metrics = got[0]
+    assert avg == pytest.approx(36.0 / 5) and metrics["ms_loss"] == pytest.approx(3 * 36.0 / 5)
+    assert metrics["total_latent_loss"] == pytest.approx(5 * 36.0 / 5)
+
+
 def _loss_inputs(meta):
     B, C, Tn, salt = meta["B"], meta["C"], meta["T"], meta["salt"]
     pred = recipe.gaussian("loss_pred", (B, C, Tn), salt + 400)
