@@ -17,7 +17,7 @@ import jatsr_amd._lib as L  # noqa: E402
 
 # operand dtype of the loaded library: bf16, or fp16 when the process runs with JAT_OPERAND_DTYPE=fp16 (the v3mod2 trainer's
 # autocast dtype; tests/test_gpu_fp16.py re-runs this module that way).  fp16 has 3 more mantissa bits: same gates hold.
-OP = torch.float16 if L.OPERAND_DTYPE == "fp16" else OP
+OP = torch.float16 if L.OPERAND_DTYPE == "fp16" else torch.bfloat16
 
 
 def dev():
@@ -88,7 +88,9 @@ def test_norm_no_modulation():
 GEMM_SHAPES = [(128, 128, 64), (256, 512, 128), (1000, 1792, 1280), (56, 1536, 256), (1035, 1280, 5120),
                (384, 256, 8192),
                # N divisible by 160 / 320 / 448 (the wide tiles), K-tile counts 1, 2, 3 (pipeline prologue / tail paths)
-               (300, 2240, 64), (300, 2240, 128), (500, 4480, 192)]
+               (300, 2240, 64), (300, 2240, 128), (500, 4480, 192),
+               # more tiles than CUs: the one-block-per-CU variants walk several tiles per block (persistent launch)
+               (4500, 4480, 128)]
 
 
 # every tile / pipeline variant of gemm.hip; JAT_TEST_VARIANTS="31,32" narrows the sweep (dev builds of the library
