@@ -12,16 +12,18 @@
 //   - XCD-aware block remap (bijective) + grouped-M tile order for L2 reuse;
 //   - tile shape is a template parameter (WM x WN waves, TM x TN 16x16 MFMA tiles per wave): the model
 //     picks, per GEMM, the shape whose tile count quantises best onto 256 CUs.
-// Two main-loop structures:
-//   PIPE 0  one barrier per K-tile, next tile's DMA in flight under the current tile's MFMAs; fragment
-//           reads scheduled by the compiler ("minimum 2-phase" loop of T3).
-//   PIPE 1/2 one barrier per K-tile placed MID-tile (1: MFMA clusters fenced by s_setprio, 2: ds_read/MFMA
-//           interleave requested with sched_group_barrier), fragments double-buffered in registers and always read
-//           one k-step ahead of the MFMAs that use them (also across the tile boundary), so no LDS latency
-//           and no DMA wait is exposed at the top of a tile:
+// Main-loop structures (template parameter PIPE; the ones measured and retired in rounds 1-2 — one barrier per K-tile
+// without register double buffering, 3-stage ring, K-tile-granular ping-pong, DMA waves without ping-pong — are in the
+// history and in DESIGN.md "what was tried"):
+//   PIPE 1/2 4-wave blocks, two per CU: one barrier per K-tile placed MID-tile (1: MFMA clusters fenced by s_setprio,
+//           2: ds_read/MFMA interleave requested with sched_group_barrier), fragments double-buffered in registers and
+//           always read one k-step ahead of the MFMAs that use them (also across the tile boundary):
 //             phase A: MFMA(F0: tile t, k-step 0)  ||  ds_read F1 <- tile t, k-step 1
 //             s_waitcnt (F1 in regs, my DMA pieces of tile t+1 landed) ; barrier ; DMA tile t+2 -> stage of t
 //             phase B: MFMA(F1)                    ||  ds_read F0 <- tile t+1, k-step 0
+//           The small and medium tiles (64x128 ... 256x256) whose two co-resident blocks hide each other's epilogue.
+//   PIPE 6  8 MFMA waves in K-tile-granular ping-pong + 4 DMA-only waves, 3 LDS stages (256x160 / 256x128).
+//   PIPE 8  quadrant ping-pong, 8 waves, 2 LDS stages: the large tiles (224x320, 256x256, 224x256, 128x448, 256x160).
 // M may be ragged (rows clamped on load, masked on store); N % BN == 0 and K % 64 == 0 are required.
 #include "jat_kernels.h"
 #include "jat_dtype.h"
@@ -113,18 +115,11 @@ __device__ __forceinline__ void rows_rstd(const GemmArgs& p, int row0, int lane,
     rstd[i] = rsqrtf(sq * invk + 1e-6f);
   }
 }
-// producer side: A'[m][n..n+3] = bf16(x) (the norm weight and the adaLN scale live in the consumer's folded weights);
-// this chunk's sum of squares goes back into its slab slot
-__device__ __forceinline__ void fold_emit(const GemmArgs& p, char* slot, float4 x, int m, int n, int b) {
-  *(uint2*)(p.fold_out + (int64_t)m * p.ldo + n) = pack4(x.x, x.y, x.z, x.w);
-  *(float*)slot = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-}
-
 // 4-wave blocks with <= 20 accumulator tiles per wave are meant to run two per CU (2 waves per SIMD): cap the
 // register allocation accordingly (2nd launch-bounds argument = waves per SIMD).
 // PIPE 6 adds 4 DMA-only waves (one per SIMD) to the 8 MFMA waves: 768 threads, three waves per SIMD.
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
-__global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
+__global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
     gemm_bf16_kernel(const GemmArgs p_in) {
   GemmArgs p = p_in;
   if (p.ksplit > 1) {   // split-K slice of this block (uniform): shift the operands along K and the output to its partial
@@ -183,29 +178,14 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
     const int koff = kt * BK;
 #pragma unroll
     for (int j = 0; j < AI; ++j)
-      if (PIPE >= 3 || PA % NW == 0 || wave + j * NW < PA)
+      if (PA % NW == 0 || wave + j * NW < PA)
         __builtin_amdgcn_global_load_lds((const void*)(a_src[j] + koff),
                                          (lds_ptr_t)(sA + min(wave + j * NW, PA - 1) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < BI; ++j)
-      if (PIPE >= 3 || PB % NW == 0 || wave + j * NW < PB)
+      if (PB % NW == 0 || wave + j * NW < PB)
         __builtin_amdgcn_global_load_lds((const void*)(b_src[j] + koff),
                                          (lds_ptr_t)(sB + min(wave + j * NW, PB - 1) * 1024), 16, 0, 0);
-  };
-
-  auto stage_a = [&](int st, int kt) {   // A pieces only (PIPE 5), uniform count per wave
-    char* sA = smem + st * STAGE;
-#pragma unroll
-    for (int j = 0; j < AI; ++j)
-      __builtin_amdgcn_global_load_lds((const void*)(a_src[j] + kt * BK),
-                                       (lds_ptr_t)(sA + min(wave + j * NW, PA - 1) * 1024), 16, 0, 0);
-  };
-  auto stage_b = [&](int st, int kt) {   // W pieces only
-    char* sB = smem + st * STAGE + A_BYTES;
-#pragma unroll
-    for (int j = 0; j < BI; ++j)
-      __builtin_amdgcn_global_load_lds((const void*)(b_src[j] + kt * BK),
-                                       (lds_ptr_t)(sB + min(wave + j * NW, PB - 1) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[TM][TN];
@@ -240,82 +220,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
   rows_rstd<TM>(p, m0 + wm * TM * 16, lane, rstd_rows);
 
   const int nk = p.K / BK;
-  if constexpr (PIPE == 0) {
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-      bf16x8 af[TM], wf[TN];
-      read_frags(af, wf, cur, coff0);
-      mma(af, wf);
-      read_frags(af, wf, cur, coff1);
-      mma(af, wf);
-    }
-  } else if constexpr (PIPE == 3) {
-    // 3-stage LDS ring, TWO K-tiles of DMA in flight under the MFMAs: counted s_waitcnt vmcnt (never 0 in the
-    // steady state) + raw s_barrier (a __syncthreads() would drain the DMA queue: "Pipelining across barriers").
-    constexpr int PW = AI + BI;  // DMA pieces per wave per K-tile (uniform: stage() pads with duplicates)
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, kt + 2);
-      bf16x8 af[TM], wf[TN];
-      read_frags(af, wf, cur, coff0);
-      mma(af, wf);
-      read_frags(af, wf, cur, coff1);
-      mma(af, wf);
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-  } else if constexpr (PIPE == 4) {
-    // Ping-pong between the two waves that share a SIMD (waves w and w+4 of an 8-wave block): time is cut into
-    // slots separated by s_barrier; in every slot one half of the block (wave group g = wave>>2, which owns one
-    // M-half of the tile) issues its MFMAs for K-tile t while the other half does its LDS fragment reads for its
-    // next K-tile and issues the DMA for tile t+2, then they swap (MI355X_MICROARCH "Two waves per SIMD";
-    // cdna_hip_programming.md 8-phase template).  3-stage LDS ring; counted vmcnt; raw barriers only.
-    //   group 0: LOAD(t) in slot 2t,   MFMA(t) in slot 2t+1      group 1: one slot later.
-    static_assert(NW == 8, "ping-pong needs two waves per SIMD in one block");
-    constexpr int PW = AI + BI;
-    const int grp = wave >> 2;
-    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      // ---- LOAD slot: fragments of both k-steps of tile kt into registers; DMA for tile kt+2
-      if (!(p.dbg & 4) || kt == 0) {
-        read_frags(a0, w0, cur, coff0);
-        read_frags(a1, w1, cur, coff1);
-      }
-      if (kt + 2 < nk && !(p.dbg & 2)) {
-        stage(cur == 0 ? 2 : cur - 1, kt + 2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // my pieces of tile kt+1 have landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      // ---- MFMA slot
-      __builtin_amdgcn_s_setprio(1);
-      mma(a0, w0);
-      mma(a1, w1);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-  } else if constexpr (PIPE == 6) {
+  if constexpr (PIPE == 6) {
     // Wave specialisation: waves 0-7 are the ping-pong MFMA waves of PIPE 4 but never touch global memory in the
     // K loop; waves 8-11 (one per SIMD) only issue the global->LDS DMA, spread evenly over every slot
     // (A pieces of tile j+2 in slot 2j, W pieces in slot 2j+1), each completing two slots before its first reader.
@@ -413,70 +318,6 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
       o[0] = tl_load; o[1] = tl_b1; o[2] = tl_mma; o[3] = tl_b2;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
-  } else if constexpr (PIPE == 7) {
-    // 8 MFMA waves + 4 DMA waves as PIPE 6, but WITHOUT ping-pong slots: the MFMA waves run the mid-tile-barrier loop
-    // of PIPE 2 (fragments one k-step ahead in registers) and never issue DMA; ONE barrier per K-tile for all 12 waves.
-    static_assert(NW == 8 && PA % 4 == 0 && PB % 4 == 0, "PIPE 7: 8 MFMA waves + 4 DMA waves");
-    constexpr int NDW = 4, AI6 = PA / NDW, BI6 = PB / NDW;
-    if (wave >= NW) {
-      const int dw = wave - NW;
-      const bf16_t* asrc[AI6];
-      const bf16_t* bsrc[BI6];
-#pragma unroll
-      for (int j = 0; j < AI6; ++j)
-        asrc[j] = p.A + (int64_t)min(m0 + (dw + j * NDW) * 8 + srow, p.M - 1) * p.lda + schunk * 8;
-#pragma unroll
-      for (int j = 0; j < BI6; ++j) bsrc[j] = p.W + (int64_t)(n0 + (dw + j * NDW) * 8 + srow) * p.ldw + schunk * 8;
-      auto issue = [&](int st, int kt) {
-#pragma unroll
-        for (int j = 0; j < AI6; ++j)
-          __builtin_amdgcn_global_load_lds((const void*)(asrc[j] + kt * BK),
-                                           (lds_ptr_t)(smem + st * STAGE + (dw + j * NDW) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < BI6; ++j)
-          __builtin_amdgcn_global_load_lds((const void*)(bsrc[j] + kt * BK),
-                                           (lds_ptr_t)(smem + st * STAGE + A_BYTES + (dw + j * NDW) * 1024), 16, 0, 0);
-      };
-      issue(0, 0);
-      if (nk > 1) {
-        issue(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI6 + BI6) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();  // tile 0 visible
-      int st = 2;
-      for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) {
-          issue(st, kt + 2);
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI6 + BI6) : "memory");  // tile kt+1 landed, tile kt+2 in flight
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        st = st == 2 ? 0 : st + 1;
-      }
-      if constexpr (CE && EPI <= EPI_QKV_ROPE) __builtin_amdgcn_s_barrier();
-      return;
-    }
-    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
-    __builtin_amdgcn_s_barrier();
-    read_frags(a0, w0, 0, coff0);
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int nxt = cur == 2 ? 0 : cur + 1;
-      read_frags(a1, w1, cur, coff1);
-      __builtin_amdgcn_s_setprio(1);
-      mma(a0, w0);
-      __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();       // tile kt+1 landed (DMA waves waited for it); stage of tile kt-1 is free
-      read_frags(a0, w0, nxt, coff0);     // harmless when kt+1 == nk
-      __builtin_amdgcn_s_setprio(1);
-      mma(a1, w1);
-      __builtin_amdgcn_s_setprio(0);
-      cur = nxt;
-    }
   } else if constexpr (PIPE == 8) {
     // Quadrant ping-pong (the "8-phase" structure of cdna_hip_programming.md §5, generalised to any TM x TN wave tile and to
     // uneven halves): the wave tile is cut into an A split (rows: TMa + TMb 16-row MFMA tiles; one part when SPLIT_M is off)
@@ -671,45 +512,6 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
 #undef JAT_LOAD_END
 #undef JAT_MMA_END
     if (grp == 0) __builtin_amdgcn_s_barrier();
-  } else if constexpr (PIPE == 5) {
-    // Ping-pong as PIPE 4, but the W pieces of tile kt+2 are issued from inside the MFMA slot (between the two
-    // k-steps), so the load slot (fragment reads + A pieces) is no longer the longer of the two slots.
-    static_assert(NW == 8, "ping-pong needs two waves per SIMD in one block");
-    const int grp = wave >> 2;
-    bf16x8 a0[TM], w0[TN], a1[TM], w1[TN];
-    stage(0, 0);
-    if (nk > 1) stage_a(1, 1);
-    if (nk > 1) stage_b(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int nxt2 = cur == 0 ? 2 : cur - 1;
-      read_frags(a0, w0, cur, coff0);
-      read_frags(a1, w1, cur, coff1);
-      if (kt + 2 < nk) {
-        stage_a(nxt2, kt + 2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI) : "memory");   // all my pieces of tile kt+1 have landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
-      mma(a0, w0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < nk) stage_b(nxt2, kt + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a1, w1);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
   } else {
     // interleave hint: one fragment read, then MPR MFMAs, ... (sched_group_barrier masks: MFMA 0x8, DS read 0x100)
     constexpr int NREAD = TM + TN, NMMA = TM * TN, MPR = NMMA / NREAD;
@@ -871,7 +673,6 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
-    constexpr bool fold = false;   // producers with fold_out take the split-residual epilogue above
     const int npass = (EPI == EPI_BF16_GELU && p.dual_rows > 0) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass)
 #pragma unroll
@@ -926,41 +727,19 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
         if (row >= grows) continue;
         if (m < p.M) {
           if constexpr (EPI == EPI_RESID) {
-            const int b = m / p.ntok;
             float4 x;
             x.x = xs[tt][0] + gs[tt][0] * __uint_as_float(raw.x); x.y = xs[tt][1] + gs[tt][1] * __uint_as_float(raw.y);
             x.z = xs[tt][2] + gs[tt][2] * __uint_as_float(raw.z); x.w = xs[tt][3] + gs[tt][3] * __uint_as_float(raw.w);
             *(float4*)((float*)p.out + (int64_t)m * p.ldo + n) = x;
-            if (fold) fold_emit(p, wbuf + row * RS + cc * 16, x, m, n, b);
           } else if constexpr (EPI == EPI_F32) {
             *(uint4*)((float*)p.out + (int64_t)m * p.ldo + n) = raw;
-            if (fold)
-              fold_emit(p, wbuf + row * RS + cc * 16,
-                        float4{__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)},
-                        m, n, m / p.ntok);
           } else {
             *(uint4*)((bf16_t*)p.out + (int64_t)(m + pass * p.dual_rows) * p.ldo + n) = raw;
           }
-        } else if (OUT32 && fold) {
-          *(float*)(wbuf + row * RS + cc * 16) = 0.f;
         }
       }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if constexpr (OUT32) {
-        // row partial sums of x_new^2 over this wave's columns, summed in a fixed order by one lane per row
-        if (fold) {  // two lanes per row, fixed order: lane 2r sums the even chunks' half, lane 2r+1 the other
-          constexpr int HALF = CPR / 2;
-          const int r = lane >> 1, h = lane & 1;
-          float sq = 0.f;
-#pragma unroll
-          for (int cc = 0; cc < HALF; ++cc) sq += *(const float*)(wbuf + r * RS + (h * HALF + cc) * 16);
-          sq += __shfl_xor(sq, 1);
-          const int m = mw0 + ig * 32 + r;
-          if (h == 0 && m < p.M && r < grows) p.fold_part[(int64_t)m * p.fold_np + nw0 / (TN * 16)] = sq;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
     }
     return;
   }
@@ -1268,7 +1047,7 @@ __global__ void __launch_bounds__((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0))
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int LDS = ((PIPE >= 3 && PIPE != 8) ? 3 : 2) * (BM + BN) * 128;
+  constexpr int LDS = (PIPE == 6 ? 3 : 2) * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   static bool attr_set = false;
   auto kern = gemm_bf16_kernel<WM, WN, TM, TN, PIPE, CE, EPI>;
@@ -1280,7 +1059,7 @@ static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (a.N % BN != 0 || a.K % 64 != 0 || a.M <= 0) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
   if (a.ksplit > 1 && EPI != EPI_F32) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit > 1 ? a.ksplit : 1), dim3((WM * WN + ((PIPE == 6 || PIPE == 7) ? 4 : 0)) * 64), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit > 1 ? a.ksplit : 1), dim3((WM * WN + (PIPE == 6 ? 4 : 0)) * 64), LDS, s, a);
   return hipGetLastError();
 }
 
@@ -1298,23 +1077,21 @@ static hipError_t launch_epi(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 // variant table: {BM, BN} per id (for the host-side chooser) and the dispatch below must stay in sync
+// Variant ids are stable across rounds (profiles and DESIGN.md cite them); retired ids have a {0, 0} tile and are rejected.
 static const int kVariantTile[][2] = {
-    {128, 128}, {256, 128}, {256, 256},              // 0-2: PIPE 0
-    {128, 128}, {128, 160}, {256, 160}, {256, 128},  // 3-6: PIPE 1
-    {256, 256}, {224, 160}, {224, 224}, {128, 64},   // 7-10: PIPE 1
-    {128, 128}, {128, 160}, {256, 160}, {224, 160},  // 11-14: PIPE 2
-    {256, 128}, {256, 160}, {256, 128},              // 15-17: PIPE 3 (3-stage ring; 17 = 2x4 waves of 128x32)
-    {128, 160}, {256, 160}, {128, 128}, {256, 256},  // 18-21: PIPE 2 + coalesced epilogue
-    {256, 160}, {256, 128},                          // 22-23: PIPE 4 (ping-pong) + coalesced epilogue
-    {256, 160},                                      // 24: PIPE 5 (ping-pong, W pieces issued in the MFMA slot)
+    {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0},   // 0-9: retired (PIPE 0 / 1)
+    {128, 64},                                                                          // 10: PIPE 1, the always-valid fallback (N % 64)
+    {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0},                             // 11-17: retired (PIPE 2 without the coalesced epilogue, PIPE 3)
+    {128, 160}, {0, 0}, {128, 128}, {256, 256},      // 18, 20, 21: PIPE 2 + coalesced epilogue (19 retired)
+    {0, 0}, {0, 0}, {0, 0},                          // 22-24: retired (PIPE 4 / 5)
     {256, 160}, {256, 128},                          // 25-26: PIPE 6 (8 MFMA waves + 4 DMA waves)
     {64, 160}, {64, 128},                            // 27-28: small-M tiles (PIPE 2 + coalesced epilogue)
-    {256, 160}, {256, 128},                          // 29-30: PIPE 7 (8 MFMA + 4 DMA waves, one barrier per K-tile)
+    {0, 0}, {0, 0},                                  // 29-30: retired (PIPE 7)
     {224, 320}, {256, 160}, {256, 256}, {128, 448},  // 31-34: PIPE 8 (quadrant ping-pong, 2 LDS stages) + coalesced epilogue
     {224, 256},                                      // 35: PIPE 8
 };
-static const int kVariantWaveN[] = {64, 64, 64, 64, 80, 80, 64, 64, 80, 112, 32, 64, 80, 80, 80, 64, 80, 32,
-                                    80, 80, 64, 64, 80, 64, 80, 80, 64, 80, 64, 80, 64, 80, 80, 64, 112, 64};
+static const int kVariantWaveN[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32, 0, 0, 0, 0, 0, 0, 0,
+                                    80, 0, 64, 64, 0, 0, 0, 80, 64, 80, 64, 0, 0, 80, 80, 64, 112, 64};
 int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
 bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
@@ -1328,51 +1105,22 @@ void gemm_variant_tile(int variant, int* bm, int* bn) {
   *bn = kVariantTile[variant][1];
 }
 
+bool gemm_variant_exists(int variant) {
+  return variant >= 0 && variant < gemm_num_variants() && kVariantTile[variant][0] != 0;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
-  if (variant < 0 || variant >= gemm_num_variants()) return hipErrorInvalidValue;
+  if (!gemm_variant_exists(variant)) return hipErrorInvalidValue;
   if (a.N % kVariantTile[variant][1] != 0) variant = (a.N % 128 == 0) ? 20 : 10;  // always-valid fallbacks
   switch (variant) {
-#ifndef JAT_DEV_VARIANTS   // dev builds (fast compile): only the variants the model picks + the new ones
-    case 0: return launch_epi<2, 2, 4, 4, 0>(a, epi, s);
-    case 1: return launch_epi<4, 2, 4, 4, 0>(a, epi, s);
-    case 2: return launch_epi<2, 4, 8, 4, 0>(a, epi, s);
-    case 3: return launch_epi<2, 2, 4, 4, 1>(a, epi, s);
-    case 4: return launch_epi<2, 2, 4, 5, 1>(a, epi, s);
-    case 5: return launch_epi<4, 2, 4, 5, 1>(a, epi, s);
-    case 6: return launch_epi<4, 2, 4, 4, 1>(a, epi, s);
-    case 7: return launch_epi<2, 4, 8, 4, 1>(a, epi, s);
-    case 8: return launch_epi<2, 2, 7, 5, 1>(a, epi, s);
-    case 9: return launch_epi<2, 2, 7, 7, 1>(a, epi, s);
-#endif
     case 10: return launch_epi<2, 2, 4, 2, 1>(a, epi, s);
-#ifndef JAT_DEV_VARIANTS
-    case 11: return launch_epi<2, 2, 4, 4, 2>(a, epi, s);
-    case 12: return launch_epi<2, 2, 4, 5, 2>(a, epi, s);
-    case 13: return launch_epi<4, 2, 4, 5, 2>(a, epi, s);
-    case 14: return launch_epi<2, 2, 7, 5, 2>(a, epi, s);
-    case 15: return launch_epi<4, 2, 4, 4, 3>(a, epi, s);
-    case 16: return launch_epi<4, 2, 4, 5, 3>(a, epi, s);
-    case 17: return launch_epi<2, 4, 8, 2, 3>(a, epi, s);
-#endif
     case 18: return launch_epi<2, 2, 4, 5, 2, 1>(a, epi, s);
-#ifndef JAT_DEV_VARIANTS
-    case 19: return launch_epi<4, 2, 4, 5, 2, 1>(a, epi, s);
-#endif
     case 20: return launch_epi<2, 2, 4, 4, 2, 1>(a, epi, s);
     case 21: return launch_epi<2, 4, 8, 4, 2, 1>(a, epi, s);
-#ifndef JAT_DEV_VARIANTS
-    case 22: return launch_epi<4, 2, 4, 5, 4, 1>(a, epi, s);
-    case 23: return launch_epi<4, 2, 4, 4, 4, 1>(a, epi, s);
-    case 24: return launch_epi<4, 2, 4, 5, 5, 1>(a, epi, s);
-#endif
     case 25: return launch_epi<4, 2, 4, 5, 6, 1>(a, epi, s);
     case 26: return launch_epi<4, 2, 4, 4, 6, 1>(a, epi, s);
     case 27: return launch_epi<2, 2, 2, 5, 2, 1>(a, epi, s);
     case 28: return launch_epi<2, 2, 2, 4, 2, 1>(a, epi, s);
-#ifndef JAT_DEV_VARIANTS
-    case 29: return launch_epi<4, 2, 4, 5, 7, 1>(a, epi, s);
-    case 30: return launch_epi<4, 2, 4, 4, 7, 1>(a, epi, s);
-#endif
     case 31: return launch_epi<2, 4, 7, 5, 8, 1>(a, epi, s);
     case 32: return launch_epi<4, 2, 4, 5, 8, 1>(a, epi, s);
     case 33: return launch_epi<2, 4, 8, 4, 8, 1>(a, epi, s);

@@ -70,6 +70,7 @@ struct GemmArgs {
 // variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s);
 int gemm_num_variants();
+bool gemm_variant_exists(int variant);   // ids of retired variants are rejected by launch_gemm
 // Fused QKV projection + RoPE + attention for ntok == 128 (W = group-major fused weight [Hkv][5*64+64+64][K]):
 // one block per (sample, KV group); a.out = attention output bf16 [M, D]; a.N = Hkv * 448.
 hipError_t launch_qkv_attn(const GemmArgs& a, hipStream_t s);

@@ -11,11 +11,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FP16_VARIANTS = "10,18,20,21,25,26,27,28,31,32,33,34,35"     # what the fp16 library instantiates (csrc/Makefile)
 
 
 def _child(args, extra_env=None, timeout=900):
-    env = dict(os.environ, JAT_OPERAND_DTYPE="fp16", JAT_TEST_VARIANTS=FP16_VARIANTS, **(extra_env or {}))
+    env = dict(os.environ, JAT_OPERAND_DTYPE="fp16", **(extra_env or {}))
     env.pop("JAT_LIB_PATH", None)
     out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=timeout)

@@ -20,7 +20,7 @@ SHAPES = {"qkv": (1792, 1280, 1), "out": (1280, 1280, 3), "fc1": (5120, 1280, 2)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", type=int, default=7168)
-    ap.add_argument("--variants", default="0,3,4,5,6,7,8,11,12,13,14")
+    ap.add_argument("--variants", default="18,21,25,31,32,33,35")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--shapes", default="qkv,out,fc1,fc2")

@@ -9,7 +9,7 @@ import jatsr_amd._lib as L
 ap = argparse.ArgumentParser()
 ap.add_argument("--M", type=int, default=7168)
 ap.add_argument("--N", type=int, default=5120)
-ap.add_argument("--variants", default="12,13")
+ap.add_argument("--variants", default="31,32")
 ap.add_argument("--Ks", default="64,320,1280,5120")
 ap.add_argument("--epis", default="0,1,2,3")
 a = ap.parse_args()

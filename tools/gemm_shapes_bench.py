@@ -18,7 +18,7 @@ import jatsr_amd._lib as L
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", required=True)
-    ap.add_argument("--variants", default="18,19,20,21,25,26,27,28")
+    ap.add_argument("--variants", default="18,20,21,25,26,27,28,31,32,33,35")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     a = ap.parse_args()
