@@ -98,6 +98,13 @@ int jat_time_embed(jat_model* m, const float* t, float* t_emb, int32_t B, void* 
 int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t steps, float cfg_scale,
                        jat_sampler** out);
 void jat_sampler_destroy(jat_sampler* s);
+/* Rows of the bucket that are SHORTER than T (the last chunk of a file, infer_test_v3m2.py:353-361,370-398, batched with
+ * the full-length chunks instead of sampled alone): frames[b] in (0, T] valid latent frames of row b; the caller zero-pads
+ * lr_latent / z0 beyond them and ignores z_out there.  Attention masks the padded keys, every other operator is row-wise,
+ * so the valid frames equal a stand-alone run of frames[b] frames.  Sticky until set again.  Not available for buckets of
+ * exactly 128 tokens that run the fused QKV+attention kernel (JAT_E_STATE). */
+int jat_sampler_set_lengths(jat_sampler* sampler, const int32_t* frames, int32_t n, void* stream);
+
 /* lr_latent, z0_noise, z_out: [B, C, T].  z0_noise replaces torch.randn at :133 (caller-supplied so that
  * results are reproducible).  use_graph=0 replays the same kernels eagerly (debug / A-B timing). */
 int jat_sampler_run(jat_sampler* s, const float* lr_latent, const float* z0_noise, float* z_out,

@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
     for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const int nkb = (N + KVB - 1) / KVB;
+  const int Nb = p.lens ? min(p.lens[b], N) : N;   // keys this sample attends to (block-uniform)
+  const int nkb = (Nb + KVB - 1) / KVB;            // same key blocks as a stand-alone run of Nb tokens
   for (int kb = 0; kb < nkb; ++kb) {
     const int key0 = kb * KVB;
     __syncthreads();  // all waves done reading the previous block
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
-          const float sv = key < N ? st[qt][kt][r] * p.scale_log2e : -1e30f;
+          const float sv = key < Nb ? st[qt][kt][r] * p.scale_log2e : -1e30f;
           st[qt][kt][r] = sv;
           mx = fmaxf(mx, sv);
         }
@@ -369,7 +370,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid((a.N + 64 * QT - 1) / (64 * QT), a.Hq, a.B);
   static const int kvb_env = getenv("JAT_ATTN_KVB") ? atoi(getenv("JAT_ATTN_KVB")) : 64;
   static const int group_env = getenv("JAT_ATTN_GROUP") ? atoi(getenv("JAT_ATTN_GROUP")) : 1;
-  if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse && !a.drop.thresh) {   // the sampler's shape: K/V staged once per KV head
+  if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse && !a.drop.thresh && !a.lens) {   // the sampler's shape: K/V staged once per KV head
     hipLaunchKernelGGL((attn_group_kernel<1, 8>), dim3(a.Hkv, a.B), dim3(512), 0, s, a);
   } else if (kvb_env == 64 || a.N <= 64) {
     hipLaunchKernelGGL((attn_fwd_kernel<QT, 64>), grid, dim3(256), 0, s, a);

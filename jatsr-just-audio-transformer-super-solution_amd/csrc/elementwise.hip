@@ -175,7 +175,7 @@ hipError_t launch_norm_modulate(const float* x, const float* w, const float* shi
 // 256-B runs along the feature dimension.  Tile = 64 tokens x 32 channels.
 __global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ x_t, const float* __restrict__ x_c,
                                                        bf16_t* __restrict__ A, int B_src, int cond_zero_from, int C_t,
-                                                       int C_c, int T_orig, int ntok) {
+                                                       int C_c, int T_orig, int ntok, const int* __restrict__ tvalid) {
   constexpr int ROW = 264;  // 32 channels x 8 B + 8 B pad: conflict-free ds_write_b64 down a column
   __shared__ __attribute__((aligned(16))) char tile[64 * ROW];
   const int tid = threadIdx.x;
@@ -193,6 +193,9 @@ __global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__
     cl = c0 - C_t;
   }
   const int tl = tid & 63, tok = tok0 + tl;
+  // frames >= tv read as zero: T_orig, or the row's own length when a short chunk is batched with longer ones (the sampler's
+  // state z evolves in the padded frames too; a stand-alone run would re-pad with zeros at every step, :435-439)
+  const int tv = tvalid ? min(tvalid[b % B_src], T_orig) : T_orig;
   const bool aligned = (T_orig & 3) == 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -200,14 +203,14 @@ __global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__
     float4 v = float4{0.f, 0.f, 0.f, 0.f};
     if (!zero && tok < ntok) {
       const float* p = src + (int64_t)(cl + ci) * T_orig + tok * 4;
-      if (aligned) {
+      const int t0 = tok * 4;
+      if (aligned && t0 + 3 < tv) {
         v = *(const float4*)p;
       } else {
-        const int t0 = tok * 4;
-        if (t0 + 0 < T_orig) v.x = p[0];
-        if (t0 + 1 < T_orig) v.y = p[1];
-        if (t0 + 2 < T_orig) v.z = p[2];
-        if (t0 + 3 < T_orig) v.w = p[3];
+        if (t0 + 0 < tv) v.x = p[0];
+        if (t0 + 1 < tv) v.y = p[1];
+        if (t0 + 2 < tv) v.z = p[2];
+        if (t0 + 3 < tv) v.w = p[3];
       }
     }
     *(uint2*)(tile + tl * ROW + ci * 8) = pack4_e(v.x, v.y, v.z, v.w);
@@ -224,11 +227,11 @@ __global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__
 }
 
 hipError_t launch_patchify(const float* x_t, const float* x_cond, bf16_t* A, int B, int B_src, int cond_zero_from,
-                           int C_t, int C_c, int T_orig, int ntok, hipStream_t s) {
+                           int C_t, int C_c, int T_orig, int ntok, hipStream_t s, const int* tvalid) {
   if (C_t % 32 != 0 || C_c % 32 != 0 || B <= 0 || B_src <= 0) return hipErrorInvalidValue;
   dim3 grid((ntok + 63) / 64, (C_t + C_c) / 32, B);
   hipLaunchKernelGGL(patchify_kernel, grid, dim3(256), 0, s, x_t, x_cond, A, B_src, cond_zero_from, C_t, C_c, T_orig,
-                     ntok);
+                     ntok, tvalid);
   return hipGetLastError();
 }
 

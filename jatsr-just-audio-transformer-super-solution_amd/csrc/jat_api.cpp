@@ -31,6 +31,8 @@ struct Workspace {
   bf16_t *a_patch, *h_patch, *xn, *xlo, *q, *k, *vt, *ao, *hm, *t_silu;
   float *x, *mod, *e_sin, *t_h, *t_emb, *part;
   float* kpart;   // split-K partials of the fc2 GEMM when M is too small to fill the chip (nullptr for large M)
+  const int* lens = nullptr;   // sampler: per-batch-row key counts (tokens) for the attention kernel, or nullptr
+  const int* tvalid = nullptr; // sampler: valid frames per source row (patchify reads zeros beyond them), or nullptr
   int npad;
   size_t vt_bytes, total;
 };
@@ -443,6 +445,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     a.q = w.q; a.k = w.k; a.vt = w.vt; a.o = w.ao; a.ldq = D; a.ldk = m->kvD; a.ldo = D;
     a.B = B; a.N = ntok; a.Hq = m->Hq; a.Hkv = m->Hkv; a.npad = w.npad;
     a.scale_log2e = 0.125f * 1.4426950408889634f;
+    a.lens = w.lens;
     KCHK(launch_attention(a, s));
   }
   {
@@ -505,12 +508,12 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
     // uncond halves and the cond part (pc = patch(lr) @ W1[:, cond]^T, fp32) does not change over the 50 steps:
     // h_cond = gelu(S_z + pc + b1), h_uncond = gelu(S_z + b1) from ONE quarter-size GEMM (M/2 rows, K/2 deep).
     const int Mh = M / 2, Kz = m->P * m->Cin;
-    KCHK(launch_patchify(x_t, nullptr, w.a_patch, B_src, B_src, B_src, m->Cin, 0, T, ntok, s));
+    KCHK(launch_patchify(x_t, nullptr, w.a_patch, B_src, B_src, B_src, m->Cin, 0, T, ntok, s, w.tvalid));
     GemmArgs e{};
     e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok; e.dual_add = pc; e.dual_rows = Mh;
     JCHK(gemm(m, G_OTHER, w.a_patch, Kz, m->pe_w1, m->Kp, Mh, m->bott, Kz, EPI_BF16_GELU, e, s));
   } else {
-    KCHK(launch_patchify(x_t, x_cond, w.a_patch, B, B_src, cond_zero_from, m->Cin, m->Cc, T, ntok, s));
+    KCHK(launch_patchify(x_t, x_cond, w.a_patch, B, B_src, cond_zero_from, m->Cin, m->Cc, T, ntok, s, w.tvalid));
     GemmArgs e{};
     e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok;
     JCHK(gemm(m, G_OTHER, w.a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16_GELU, e, s));
@@ -622,6 +625,8 @@ struct jat_sampler {
   std::shared_ptr<FoldTable> fold;   // per-step folded weights (RMSNorm models), shared through the model's cache
   bool fused_attn = false;           // this bucket runs the fused QKV+attention kernel (group-major folded weights)
   float* pc = nullptr;   // CFG: patch(lr) @ W1[:, cond]^T, recomputed once per run (split patch embed)
+  int* lens_dev = nullptr;   // [Bf] valid tokens per batch row (default: ntok), read by the attention kernel of the graph
+  int* frames_dev = nullptr; // [B] valid frames per row (default: T), read by the patchify kernels
   bool folded = false;
   void* ws;
   size_t ws_bytes;
@@ -645,7 +650,7 @@ static int sampler_cond_part(jat_sampler* sp, hipStream_t s) {
   if (!sp->pc) return JAT_OK;
   jat_model* m = sp->m;
   const int ntok = (sp->T + 3) / 4, Kc = m->P * m->Cc;
-  KCHK(launch_patchify(sp->lr, nullptr, sp->w.a_patch, sp->B, sp->B, sp->B, m->Cc, 0, sp->T, ntok, s));
+  KCHK(launch_patchify(sp->lr, nullptr, sp->w.a_patch, sp->B, sp->B, sp->B, m->Cc, 0, sp->T, ntok, s, sp->w.tvalid));
   GemmArgs e{};
   e.out = sp->pc; e.ldo = m->bott; e.ntok = ntok;
   return gemm(m, G_OTHER, sp->w.a_patch, Kc, m->pe_w1 + (int64_t)m->P * m->Cin, m->Kp, sp->B * ntok, m->bott, Kc, EPI_F32, e, s);
@@ -788,6 +793,7 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
     sp->fused_attn = fuse_env && m->Hq / m->Hkv == 5 && !m->group_copy_stale && ntok == 128 && (sp->Bf * m->Hkv >= 192 || fuse_env == 2);
   }
   const size_t o_sh = take((size_t)steps * m->D * 2);
+  const size_t o_lens = take((size_t)sp->Bf * 4), o_frames = take((size_t)B * 4);
   const size_t o_pc = take((size_t)B * ntok * m->bott * 4);
   hipError_t e = hipMalloc((void**)&sp->blob, off);
   if (e != hipSuccess) { delete sp; return fail(JAT_E_HIP, "hipMalloc(%zu): %s", off, hipGetErrorString(e)); }
@@ -795,6 +801,8 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   sp->mod_table = (float*)(sp->blob + o_tab); sp->ts_dev = (float*)(sp->blob + o_ts);
   sp->ws = sp->blob + o_ws; sp->ws_bytes = ws_bytes;
   bf16_t* sh_bf16 = (bf16_t*)(sp->blob + o_sh);
+  sp->lens_dev = (int*)(sp->blob + o_lens);
+  sp->frames_dev = (int*)(sp->blob + o_frames);
   static const int split_env = getenv("JAT_SPLIT_PATCH") ? atoi(getenv("JAT_SPLIT_PATCH")) : 1;
   if (sp->use_cfg && split_env) sp->pc = (float*)(sp->blob + o_pc);
 
@@ -827,6 +835,15 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   }
   sp->w = carve(m, sp->Bf, ntok, (char*)sp->ws);
   if (hipMemsetAsync(sp->w.vt, 0, sp->w.vt_bytes, s) != hipSuccess) return bail(fail(JAT_E_HIP, "memset vt"));
+  {  // every row attends to all of its ntok keys until jat_sampler_set_lengths says otherwise; the fused QKV+attention
+     // kernel (ntok == 128) has no key mask and is never combined with lengths
+    std::vector<int> full((size_t)sp->Bf, ntok), fullT((size_t)B, T);
+    if (hipMemcpyAsync(sp->lens_dev, full.data(), full.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(sp->frames_dev, fullT.data(), fullT.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return bail(fail(JAT_E_HIP, "lengths upload"));
+    if (!sp->fused_attn) { sp->w.lens = sp->lens_dev; sp->w.tvalid = sp->frames_dev; }
+  }
 
   // one eager pass first: sets every kernel's function attributes outside of capture and validates launches
   if (hipMemsetAsync(sp->z, 0, lat, s) != hipSuccess || hipMemsetAsync(sp->lr, 0, lat, s) != hipSuccess)
@@ -851,6 +868,27 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   e = hipGraphInstantiate(&sp->exec, sp->graph, nullptr, nullptr, 0);
   if (e != hipSuccess) return bail(fail(JAT_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)));
   *out = sp;
+  return JAT_OK;
+}
+
+extern "C" int jat_sampler_set_lengths(jat_sampler* sp, const int32_t* frames, int32_t n, void* stream) {
+  if (!sp || !frames) return fail(JAT_E_INVALID, "null argument");
+  if (n != sp->B) return fail(JAT_E_INVALID, "need one length per batch row (%d), got %d", sp->B, n);
+  const int ntok = (sp->T + 3) / 4;
+  std::vector<int> tok((size_t)sp->Bf);
+  bool all_full = true;
+  for (int b = 0; b < sp->B; ++b) {
+    if (frames[b] <= 0 || frames[b] > sp->T) return fail(JAT_E_INVALID, "length %d of row %d outside (0, %d]", frames[b], b, sp->T);
+    tok[b] = (frames[b] + 3) / 4;                       // the reference pads a chunk to a multiple of 4 frames (:435-439)
+    if (sp->use_cfg) tok[sp->B + b] = tok[b];           // CFG double batch [cond ; uncond]
+    all_full = all_full && tok[b] == ntok;
+  }
+  if (sp->fused_attn && !all_full)
+    return fail(JAT_E_STATE, "this bucket runs the fused QKV+attention kernel (128 tokens), which has no key mask");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(sp->lens_dev, tok.data(), tok.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(sp->frames_dev, frames, (size_t)sp->B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));                      // `tok` / `frames` are host memory of the caller
   return JAT_OK;
 }
 

@@ -89,6 +89,8 @@ struct AttnArgs {
   float scale_log2e; // (1/sqrt(64)) * log2(e)
   float* lse;        // optional [B, Hq, N] fp32: log2-domain log-sum-exp per query row (training forward), else nullptr
   DropSpec drop;     // training: dropout on the attention probabilities (thresh == 0: off); element ((b*Hq+h)*N + q)*N + key
+  const int* lens;   // optional [B] (device): sample b attends to keys < lens[b] only (a short chunk padded into a batch of
+                     // longer ones, infer_test_v3m2.py:370-398: the reference runs it alone, unpadded); nullptr: all N keys
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -99,8 +101,10 @@ hipError_t launch_norm_modulate(const float* x, const float* w, const float* shi
                                 hipStream_t s);
 // A[m=(b,tok)][k=c*4+p] = bf16(x[b][c][4*tok+p]) for the concatenated [x_t ; x_cond] channels.
 // x_t batch index = b % B_src; x_cond batch index = b (b < cond_zero_from) else zeros (CFG uncond half).
+// tvalid: optional device [B_src]: frames >= tvalid[b % B_src] of batch row b read as zero (rows shorter than T_orig).
 hipError_t launch_patchify(const float* x_t, const float* x_cond, bf16_t* A, int B, int B_src,
-                           int cond_zero_from, int C_t, int C_c, int T_orig, int ntok, hipStream_t s);
+                           int cond_zero_from, int C_t, int C_c, int T_orig, int ntok, hipStream_t s,
+                           const int* tvalid = nullptr);
 // sinusoidal embedding: e[b][i] = sin(t[b]*f_i), e[b][half+i] = cos(t[b]*f_i)  (jat_audiosr_v3.py:194-207)
 hipError_t launch_time_sinusoid(const float* t, float* e, int B, int D, hipStream_t s);
 // out[b][n] = act_out(sum_k in[b][k]*W[n][k] + bias[n]) in fp32; act_out: 0 none, 1 SiLU.

@@ -31,6 +31,7 @@ class Sampler:
         h = self.model._get_handle()
         self._handle = h
         self._version = (h.version, getattr(h, "epoch", 0))   # epoch: bumped by jatsr_amd.train after every weight update
+        self._lengths = None                                  # per-row valid frames currently set in the C-side sampler
         L.check(L.lib().jat_sampler_create(h.ptr, self.B, self.T, self.steps, self.cfg_scale, C.byref(self.ptr)))
 
     def _destroy(self):
@@ -44,7 +45,9 @@ class Sampler:
         except Exception:
             pass
 
-    def run(self, lr_latent, z0, use_graph=True):
+    def run(self, lr_latent, z0, use_graph=True, lengths=None):
+        """lengths: optional valid frame count per batch row (rows shorter than the bucket's T, zero-padded by the caller:
+        the last chunk of a file batched with the full-length ones).  Their valid frames equal a stand-alone run."""
         lr_latent = lr_latent.detach().to(torch.float32).contiguous()
         z0 = z0.detach().to(torch.float32).contiguous()
         if tuple(lr_latent.shape) != (self.B, self.model.input_channels, self.T) or z0.shape != lr_latent.shape:
@@ -55,6 +58,14 @@ class Sampler:
         h = self.model._get_handle()
         if (h.version, getattr(h, "epoch", 0)) != self._version:
             self._build()
+        if lengths is None and self._lengths is not None:
+            lengths = [self.T] * self.B                     # back to full-length rows
+        if lengths is not None:
+            lengths = [int(v) for v in lengths]
+            if lengths != self._lengths:
+                arr = (C.c_int32 * self.B)(*lengths)
+                L.check(L.lib().jat_sampler_set_lengths(self.ptr, arr, self.B, L.stream_ptr()))
+                self._lengths = lengths if any(v != self.T for v in lengths) else None
         out = torch.empty_like(z0)
         L.check(L.lib().jat_sampler_run(self.ptr, L.ptr(lr_latent), L.ptr(z0), L.ptr(out), 1 if use_graph else 0,
                                         L.stream_ptr()))
@@ -74,7 +85,7 @@ def _cached_sampler(model, B, T, num_steps, cfg_scale):
 
 @torch.no_grad()
 def flow_matching_sample(model, lr_latent, num_steps=50, cfg_scale=1.0, device="cuda", verbose=True, z0=None,
-                         use_graph=True):
+                         use_graph=True, lengths=None):
     """Flow-matching Euler sampling with CFG (x-prediction), reference infer_test_v3m2.py:107-185.
 
     lr_latent: [B, C, T] normalised LR latent.  Returns the generated [B, C, T] latent.
@@ -87,7 +98,7 @@ def flow_matching_sample(model, lr_latent, num_steps=50, cfg_scale=1.0, device="
     if verbose:
         print(f"  Flow Matching sampling ({num_steps} steps, CFG scale={cfg_scale}) [hipGraph={bool(use_graph)}]")
     s = _cached_sampler(model, B, T, num_steps, cfg_scale)
-    return s.run(lr_latent, z0.to(lr_latent.device), use_graph=use_graph)
+    return s.run(lr_latent, z0.to(lr_latent.device), use_graph=use_graph, lengths=lengths)
 
 
 def crossfade_chunks(chunks, overlap_frames):
@@ -129,9 +140,10 @@ def channel_affine(x, mean, std, inverse=False):
 
 @torch.no_grad()
 def sample_long(model, lr_latent, hr_mean, hr_std, lr_mean, lr_std, num_steps=50, cfg_scale=1.0,
-                chunk_frames=1378, overlap_frames=172, noise=None):
-    """Chunked long-sequence inference == the chunk loop of infer_test_v3m2.py:340-404, with chunks of equal
-    length BATCHED into one sampler launch instead of the reference's serial B=1 loop.
+                chunk_frames=1378, overlap_frames=172, noise=None, pad_short_chunks=True):
+    """Chunked long-sequence inference == the chunk loop of infer_test_v3m2.py:340-404, with the chunks of a file
+    BATCHED into one sampler launch instead of the reference's serial B=1 loop (pad_short_chunks=False: one launch
+    per distinct chunk length, the round-1 behaviour).
 
     lr_latent: [C, T_total] un-normalised latent.  noise: optional list of per-chunk z0 tensors [1,C,T_i].
     Returns [1, C, T_total] de-normalised generated latent.
@@ -139,15 +151,44 @@ def sample_long(model, lr_latent, hr_mean, hr_std, lr_mean, lr_std, num_steps=50
     Cc, total = lr_latent.shape
     plan = chunk_plan(total, chunk_frames, overlap_frames)
     lr = lr_latent.unsqueeze(0)
-    by_len = {}
-    for i, (a, b) in enumerate(plan):
-        by_len.setdefault(b - a, []).append(i)
+    lens = [b - a for a, b in plan]
     outs = [None] * len(plan)
-    for length, idxs in by_len.items():
-        batch = torch.cat([channel_affine(lr[:, :, plan[i][0]:plan[i][1]], lr_mean, lr_std) for i in idxs], 0)
-        z0 = None if noise is None else torch.cat([noise[i] for i in idxs], 0)
-        gen = flow_matching_sample(model, batch, num_steps, cfg_scale, device=batch.device, verbose=False, z0=z0)
+    # One bucket per chunk length ... except that a SHORTER last chunk rides along with the full-length ones, zero-padded,
+    # its padded keys masked in attention and its padded frames read as zeros (`Sampler.run(lengths=...)`): one launch for
+    # the whole file instead of a second, latency-bound one for a few hundred frames.  A bucket of exactly 128 tokens
+    # runs the fused QKV+attention kernel, which has no key mask: there the short chunk keeps its own bucket.
+    Tmax = max(lens)
+    merge = pad_short_chunks and len(set(lens)) > 1 and (Tmax + 3) // 4 != 128
+    groups = {Tmax: list(range(len(plan)))} if merge else {}
+    if not merge:
+        for i, n in enumerate(lens):
+            groups.setdefault(n, []).append(i)
+    for length, idxs in groups.items():
+        rows, noise_rows = [], []
+        for i in idxs:
+            c = channel_affine(lr[:, :, plan[i][0]:plan[i][1]], lr_mean, lr_std)
+            z = None if noise is None else noise[i]
+            if lens[i] < length:                       # zero-pad to the bucket's T (containers only: no arithmetic here)
+                cp = torch.zeros(1, Cc, length, dtype=c.dtype, device=c.device)
+                cp[:, :, :lens[i]] = c
+                c = cp
+                if z is not None:
+                    zp = torch.zeros(1, Cc, length, dtype=z.dtype, device=z.device)
+                    zp[:, :, :lens[i]] = z
+                    z = zp
+            rows.append(c)
+            noise_rows.append(z)
+        batch = torch.cat(rows, 0)
+        if noise is None:
+            z0 = torch.randn(batch.shape, device=batch.device)
+            for j, i in enumerate(idxs):
+                z0[j, :, lens[i]:] = 0
+        else:
+            z0 = torch.cat(noise_rows, 0)
+        row_lens = [lens[i] for i in idxs]
+        gen = flow_matching_sample(model, batch, num_steps, cfg_scale, device=batch.device, verbose=False, z0=z0,
+                                   lengths=row_lens if any(v != length for v in row_lens) else None)
         gen = channel_affine(gen, hr_mean, hr_std, inverse=True)
         for j, i in enumerate(idxs):
-            outs[i] = gen[j:j + 1]
+            outs[i] = gen[j:j + 1, :, :lens[i]].contiguous()
     return crossfade_chunks(outs, overlap_frames)

@@ -273,6 +273,45 @@ def test_sampler_at_benchmarked_shape_vs_reference_golden():
     assert torch.equal(p28[:2], g28[:2])
 
 
+def test_short_row_in_a_longer_bucket_equals_its_stand_alone_run():
+    """`Sampler.run(lengths=...)`: a row with fewer valid frames than the bucket's T (zero-padded; its padded keys masked in
+    attention, its padded frames read as zeros by the patchify kernel at every step) must reproduce the stand-alone sampling
+    of that row — including T_i % 4 != 0, where the reference re-pads the state with zeros at every step
+    (jat_audiosr_v3.py:435-439) — and leave the full-length rows bit-identical to a run without lengths."""
+    m = build("micro")
+    Cc, T = 32, 92                     # 23 tokens
+    for short in (50, 37, 4):          # 50 = 12.5 tokens (ragged), 37 (ragged), 4 (a single token)
+        lr = recipe.gaussian("len_lr", (3, Cc, T), short)
+        z0 = recipe.gaussian("len_z0", (3, Cc, T), short + 100)
+        lr[1, :, short:] = 0
+        z0[1, :, short:] = 0
+        kw = dict(num_steps=6, cfg_scale=2.5, verbose=False)
+        both = jatsr_amd.flow_matching_sample(m, cuda(lr), z0=cuda(z0), lengths=[T, short, T], **kw)
+        alone = jatsr_amd.flow_matching_sample(m, cuda(lr[1:2, :, :short]), z0=cuda(z0[1:2, :, :short]), **kw)
+        full = jatsr_amd.flow_matching_sample(m, cuda(lr[[0, 2]]), z0=cuda(z0[[0, 2]]), **kw)
+        assert rel_l2(both[1:2, :, :short].cpu().numpy(), alone.cpu().numpy()) < 2e-5
+        assert torch.equal(both[[0, 2]], full)
+    with pytest.raises(ValueError):
+        jatsr_amd.flow_matching_sample(m, cuda(lr), z0=cuda(z0), lengths=[T, T + 1, T], **kw)
+
+
+def test_sample_long_pads_the_short_tail_into_the_main_bucket():
+    """Default `sample_long`: the file's shorter last chunk rides in the same launch as the full-length chunks (one bucket);
+    same result as one launch per chunk length (`pad_short_chunks=False`) and as the chunk-by-chunk loop."""
+    m = build("micro")
+    Cc, total, chunk, ov = 32, 100, 40, 8
+    lr = cuda(recipe.gaussian("long_lr", (Cc, total), 1) * 2 + 0.3)
+    mean = cuda(recipe.gaussian("mean", (Cc,), 2) * 0.1)
+    std = cuda(np.abs(recipe.gaussian("std", (Cc,), 3)) + 0.5)
+    plan = jatsr_amd.chunk_plan(total, chunk, ov)
+    noise = [cuda(recipe.gaussian("noise", (1, Cc, b - a), i)) for i, (a, b) in enumerate(plan)]
+    kw = dict(num_steps=4, cfg_scale=2.0, chunk_frames=chunk, overlap_frames=ov, noise=noise)
+    merged = jatsr_amd.sample_long(m, lr, mean, std, mean, std, **kw)
+    split = jatsr_amd.sample_long(m, lr, mean, std, mean, std, pad_short_chunks=False, **kw)
+    assert merged.shape == split.shape == (1, Cc, total)
+    assert rel_l2(merged.cpu().numpy(), split.cpu().numpy()) < 2e-5
+
+
 def test_sample_long_at_v3mod2_dims_batched_equals_chunk_by_chunk():
     """BASELINE configs[4] dims: one file of T = 4096 latent frames, v3mod2 model, reference chunk plan (3 x 1378 + 478
     frames, overlap 172; infer_test_v3m2.py:340-404).  `sample_long` batches the equal-length chunks into one sampler
@@ -298,9 +337,16 @@ def test_sample_long_at_v3mod2_dims_batched_equals_chunk_by_chunk():
     r = rel_l2(g, ref)
     print(f"sample_long v3mod2 T=4096: batched vs chunk-by-chunk rel-L2 {r:.3e}")
     assert r < 1e-2
-    # the short last chunk is its own bucket in both runs: its un-faded tail differs only by the de-normalisation's
-    # rounding (fused multiply-add in jat_channel_affine vs torch's mul + add)
-    assert np.allclose(g[:, :, 3618 + 172:], outs[3][:, :, 172:], rtol=0, atol=4e-6)
+    # the short last chunk (478 frames) rides in the same launch as the three full chunks, zero-padded and key-masked
+    # (`sample_long(pad_short_chunks=True)`): its un-faded tail must match the stand-alone B = 1 run of 478 frames
+    tail = rel_l2(g[:, :, 3618 + 172:], outs[3][:, :, 172:])
+    print(f"short tail chunk, padded into the 1378-frame bucket vs stand-alone: rel-L2 {tail:.3e}")
+    assert tail < 1e-2
+    # and with one launch per chunk length it is the very same bucket as the stand-alone run: equal up to the
+    # de-normalisation's rounding (fused multiply-add in jat_channel_affine vs torch's mul + add)
+    split = jatsr_amd.sample_long(m, lr, mean, std, mean, std, num_steps=3, cfg_scale=3.0, noise=noise,
+                                  pad_short_chunks=False).cpu().numpy()
+    assert np.allclose(split[:, :, 3618 + 172:], outs[3][:, :, 172:], rtol=0, atol=4e-6)
 
 
 def test_graph_replay_is_deterministic():
