@@ -125,8 +125,10 @@ def main():
     ap.add_argument("--no-long", action="store_true", help="skip the T=4096 chunked-inference leg (configs[4])")
     ap.add_argument("--eager", action="store_true", help="replay the sampler without the hipGraph (A/B)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (configs[3])")
-    ap.add_argument("--mode", choices=["sample", "train"], default="sample",
-                    help="train: time K DDP training steps on every rank instead (configs[3]; not the headline metric)")
+    ap.add_argument("--mode", choices=["sample", "train", "long"], default="sample",
+                    help="train: time K DDP training steps on every rank instead (configs[3]; not the headline metric); "
+                         "long: one file of --long-T latent frames, its chunks sharded over the ranks (configs[4])")
+    ap.add_argument("--long-T", type=int, default=4096)
     ap.add_argument("--train-T", type=int, default=1378)
     ap.add_argument("--latent-loss", type=float, default=0.3, help="--mode train: latent perceptual loss weight (0 = MSE)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -185,6 +187,66 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.mode == "long":
+        # configs[4]: ONE long file, reference chunk plan (1378-frame chunks, 172 overlap); rank r samples chunks r, r + W, ...
+        # (dist.sample_long_sharded: no collective in the sampling loop, one object gather per file), rank 0 crossfades.
+        # With one rank this is jatsr_amd.sample_long: every chunk of the file in ONE launch (short tail padded + masked).
+        from jatsr_amd.dist import sample_long_sharded
+        del sampler
+        T_long = args.long_T
+        lr_long = torch.from_numpy(recipe.gaussian("lr_long", (C_lat, T_long), 9)).to(dev)
+        mean, std = torch.zeros(C_lat, device=dev), torch.ones(C_lat, device=dev)
+        plan = jatsr_amd.chunk_plan(T_long)
+        noise = [torch.from_numpy(recipe.gaussian("noise_long", (1, C_lat, b - a), i)).to(dev) for i, (a, b) in enumerate(plan)]
+
+        def sample_chunks(idxs):
+            """This rank's chunks, batched into one launch (rows shorter than the longest one padded + key-masked)."""
+            if not idxs:
+                return {}
+            Tm = max(plan[i][1] - plan[i][0] for i in idxs)
+            lens = [plan[i][1] - plan[i][0] for i in idxs]
+            lrb = torch.zeros(len(idxs), C_lat, Tm, device=dev)
+            zb = torch.zeros(len(idxs), C_lat, Tm, device=dev)
+            for j, i in enumerate(idxs):
+                lrb[j, :, :lens[j]] = jatsr_amd.channel_affine(lr_long[None, :, plan[i][0]:plan[i][1]], mean, std)[0]
+                zb[j, :, :lens[j]] = noise[i][0]
+            use_lens = any(v != Tm for v in lens) and (Tm + 3) // 4 != 128
+            gen = jatsr_amd.flow_matching_sample(model, lrb, args.num_steps, args.cfg_scale, device=dev, verbose=False, z0=zb,
+                                                 lengths=lens if use_lens else None)
+            gen = jatsr_amd.channel_affine(gen, mean, std, inverse=True)
+            return {i: gen[j:j + 1, :, :lens[j]].contiguous() for j, i in enumerate(idxs)}
+
+        def one_file():
+            chunks = sample_long_sharded(sample_chunks, plan)
+            return jatsr_amd.crossfade_chunks([c.to(dev) for c in chunks], 172) if rank == 0 else None
+        for _ in range(max(args.warmup, 1)):
+            out = one_file()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out = one_file()
+        barrier()
+        elapsed = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        if rank == 0:
+            assert out.shape == (1, C_lat, T_long) and bool(torch.isfinite(out).all())
+            print(json.dumps({
+                "metric": "DiT long-sequence latent-frames/sec (one file, T=%d, 50-step CFG)" % T_long,
+                "value": T_long * args.steps / elapsed, "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": L.operand_dtype(), "data": "synthetic",
+                "config": {"workload": f"{args.config} chunked inference of one file, T={T_long} -> chunks "
+                                       f"{[b - a for a, b in plan]}, {args.num_steps}-step CFG={args.cfg_scale}, chunks "
+                                       f"sharded round-robin over {world} rank(s), gathered once per file, crossfade on rank 0",
+                           "parallelism": f"chunk-sharded x{world}", "rccl_ranks": ranks_seen}}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if args.mode == "train":
         # configs[3]: DDP training step, B per GPU, gradient all-reduce over RCCL overlapped with the backward.
