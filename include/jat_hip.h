@@ -191,6 +191,12 @@ int jat_k_norm_modulate(const float* x, const float* w, const float* shift, cons
 int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N,
                int32_t K, int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch,
                int32_t variant, void* stream);
+/* Weight gradient of y = x W^T + b from token-major operands: dW[out,in] = dY[tokens,out]^T X[tokens,in] (fp32), db[out] =
+ * column sums of dY (db may be NULL).  out and in multiples of 128; ksplit >= 1 slices of the token axis summed in order
+ * (0 = the count that fills the chip, at most 16); work: 256 + (ksplit > 1 ? ksplit*out*in*4 : 0) + 32*out*4 bytes.  (The backward of every nn.Linear of
+ * models/JaT_V3.py under train_ddp_v3m2.py:601.) */
+int jat_k_weight_grad(const uint16_t* dY, const uint16_t* X, float* dW, float* db, int32_t tokens, int32_t out, int32_t in,
+                      int32_t ksplit, void* work, size_t work_bytes, void* stream);
 /* GQA attention on bf16 q[M,Hq*64], k[M,Hkv*64], vt[B,Hkv,64,Npad] -> o[M,Hq*64]; softmax(q k^T / 8) v. */
 int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t B,
                     int32_t N, int32_t Hq, int32_t Hkv, int32_t Npad, void* stream);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "jat_crossfade_pair": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _VP, _I32, _VP]),
     "jat_k_norm_modulate": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _I32, _I32, _I32, _VP]),
     "jat_k_gemm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _I64, _I32, _I32, _VP]),
+    "jat_k_weight_grad": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "jat_k_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "jat_k_cast_bf16": (C.c_int, [_VP, _VP, _I64, _VP]),
     "jat_k_latent_loss": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32] + [C.c_double] * 7 + [_F32, _VP, _SZ, _VP]),

@@ -949,6 +949,24 @@ extern "C" int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bia
   KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
   return JAT_OK;
 }
+extern "C" int jat_k_weight_grad(const uint16_t* dY, const uint16_t* X, float* dW, float* db, int32_t tokens, int32_t out,
+                                 int32_t in, int32_t ksplit, void* work, size_t work_bytes, void* stream) {
+  if (!gemm_tn_supports(out, in)) return fail(JAT_E_INVALID, "out and in must be multiples of 128");
+  if (tokens <= 0) return fail(JAT_E_INVALID, "tokens must be positive");
+  if (ksplit == 0) ksplit = gemm_tn_ksplit(out, in, tokens);
+  if (ksplit < 1 || ksplit > (tokens + 63) / 64) return fail(JAT_E_INVALID, "bad ksplit");
+  const int64_t area = (int64_t)out * in;
+  const size_t part_f = ksplit > 1 ? (size_t)ksplit * area : 0, col_f = db ? (size_t)colsum_slices(tokens) * out : 0;
+  const size_t need = 256 + (part_f + col_f) * 4;
+  if (!work || work_bytes < need) return fail(JAT_E_INVALID, "work needs %zu bytes", need);
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(work, 0, 256, s));   // the zero cell ragged token tiles are padded from
+  float* part = (float*)((char*)work + 256);
+  KCHK(launch_gemm_tn(dY, out, X, in, ksplit > 1 ? part : dW, in, out, in, tokens, ksplit, area, work, s));
+  if (ksplit > 1) KCHK(launch_sum_partials(part, ksplit, area, dW, area, s));
+  if (db) KCHK(launch_colsum_bf16(dY, out, tokens, out, part + part_f, db, s));
+  return JAT_OK;
+}
 extern "C" int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t B,
                                int32_t N, int32_t Hq, int32_t Hkv, int32_t Npad, void* stream) {
   AttnArgs a{};

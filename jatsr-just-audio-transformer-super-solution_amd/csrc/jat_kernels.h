@@ -139,6 +139,16 @@ hipError_t launch_crossfade_pair(const float* prev, int Tp, const float* cur, in
 hipError_t launch_sum_partials(const float* part, int nsplit, int64_t stride, float* out, int64_t n, hipStream_t s);
 hipError_t launch_transpose_bf16(const bf16_t* in, int64_t ld_in, int M, int C, bf16_t* out, int Mpad, hipStream_t s);
 hipError_t launch_rowsum_bf16(const bf16_t* x, int64_t ld, int R, int n, float* out, hipStream_t s);
+// gemm_tn.hip: dW[M,N] fp32 = dY[K,M]^T X[K,N] straight from the token-major operands (no transposed copies), optional
+// split-K partial slices; column sums of a token-major matrix (bias gradients) with colsum_slices(R) * C floats of scratch
+bool gemm_tn_supports(int M, int N);
+// zeros: >= 16 zero bytes of device memory (needed by the 256 x 256 form; nullptr keeps the 128 x 128 kernel);
+// gemm_tn_ksplit: the slice count that fills the chip for this shape
+int gemm_tn_ksplit(int M, int N, int K);
+hipError_t launch_gemm_tn(const bf16_t* dY, int64_t ldy, const bf16_t* X, int64_t ldx, float* dW, int64_t ldo, int M, int N, int K,
+                          int ksplit, int64_t split_stride, const void* zeros, hipStream_t s);
+int colsum_slices(int R);
+hipError_t launch_colsum_bf16(const bf16_t* x, int64_t ld, int R, int C, float* part, float* out, hipStream_t s);
 hipError_t launch_gelu_bf16(const bf16_t* in, bf16_t* out, int64_t n, DropSpec drop, hipStream_t s);
 hipError_t launch_gelu_bwd(const bf16_t* pre, bf16_t* d, int64_t n, DropSpec drop, hipStream_t s);
 hipError_t launch_resid_gate(const float* x_in, const bf16_t* y, const float* gate, int64_t gate_bstride, float* x_out,

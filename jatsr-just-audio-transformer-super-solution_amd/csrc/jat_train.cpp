@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -63,6 +64,9 @@ struct jat_trainer {
   float2* tw = nullptr;                // [T] twiddles
   float *ll_part = nullptr, *terms = nullptr;
   float* dw_split = nullptr;           // split-K partials of the small dW GEMMs
+  const void* zero_cell = nullptr;     // 256 zero bytes (the workspace is zeroed once and this cell is never written)
+  float* colsum_part = nullptr;        // row-slice partials of the bias-gradient column sums
+  bool tn_dw = true;                   // dW straight from token-major operands (JAT_TN_DW=0: transposed copies + gemm_bf16_kernel)
   float* dkv_part = nullptr;           // per-query-head fp32 partials of dK / dV (attention backward)
   int64_t split4_area = 0, split2_area = 0;
 };
@@ -115,11 +119,18 @@ int repack(jat_trainer* tr, hipStream_t s) {
 
 // dW[out,in] = dY^T X and (optionally) db[out] = column sums of dY, from dY bf16 [M,out] and X bf16 [M,in]
 int weight_grad(jat_trainer* tr, const bf16_t* dY, int out, const bf16_t* X, int in, float* dW, float* db, hipStream_t s) {
-  KCHK(launch_transpose_bf16(dY, out, tr->M, out, tr->tA, tr->Mpad, s));
-  KCHK(launch_transpose_bf16(X, in, tr->M, in, tr->tB, tr->Mpad, s));
   // M x N tiles of a small weight do not fill 256 CUs while K = all tokens is long: split K, sum the partials in order
   const int64_t area = (int64_t)out * in;
   const int split = area <= tr->split4_area ? 4 : (area <= tr->split2_area ? 2 : 1);
+  if (tr->tn_dw && gemm_tn_supports(out, in)) {   // straight from the token-major operands (gemm_tn.hip)
+    const int ks = gemm_tn_ksplit(out, in, tr->M);
+    KCHK(launch_gemm_tn(dY, out, X, in, ks > 1 ? tr->dw_split : dW, in, out, in, tr->M, ks, area, tr->zero_cell, s));
+    if (ks > 1) KCHK(launch_sum_partials(tr->dw_split, ks, area, dW, area, s));
+    if (db) KCHK(launch_colsum_bf16(dY, out, tr->M, out, tr->colsum_part, db, s));
+    return JAT_OK;
+  }
+  KCHK(launch_transpose_bf16(dY, out, tr->M, out, tr->tA, tr->Mpad, s));
+  KCHK(launch_transpose_bf16(X, in, tr->M, in, tr->tB, tr->Mpad, s));
   GemmArgs e{};
   e.ldo = in; e.ntok = out;
   if (split > 1) {
@@ -380,6 +391,7 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     rc = fail(JAT_E_INVALID, "%d parameters given, %zu belong to this model: every trainable tensor must be known", n, used);
   if (rc != JAT_OK) { delete tr; return rc; }
 
+  if (const char* e = getenv("JAT_TN_DW")) tr->tn_dw = atoi(e) != 0;
   // ---- one allocation: transposed weights, saved activations, backward scratch ----
   for (int pass = 0; pass < 2; ++pass) {
     size_t o = 0;
@@ -431,7 +443,14 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     tr->split4_area = (int64_t)Nqkv * D;            // q/k/v, out_proj, patch-embed proj.2: 4 slices
     tr->split2_area = (int64_t)m->Fout * D;         // final Linear: 2 slices; the MLP weights fill the chip unsplit
     if (tr->split2_area < tr->split4_area) tr->split2_area = tr->split4_area;
-    tr->dw_split = (float*)take((size_t)std::max(4 * tr->split4_area, 2 * tr->split2_area) * 4);
+    {
+      size_t need = (size_t)std::max(4 * tr->split4_area, 2 * tr->split2_area);
+      const int shapes[][2] = {{m->Fout, D}, {D, mlp}, {mlp, D}, {D, D}, {Nqkv, D}, {D, m->bott}, {m->bott, m->Kp}};
+      for (auto& sh : shapes)
+        if (gemm_tn_supports(sh[0], sh[1])) need = std::max(need, (size_t)gemm_tn_ksplit(sh[0], sh[1], M) * sh[0] * sh[1]);
+      tr->dw_split = (float*)take(need * 4);
+    }
+    tr->zero_cell = take(256);
     tr->copy_jobs = (CopyJob*)take((size_t)(8 + 5 * depth + 2) * sizeof(CopyJob));
     tr->dy = (bf16_t*)take(MD2); tr->dh = (bf16_t*)take((size_t)M * std::max(mlp, bott) * 2);
     tr->dxn = (bf16_t*)take(MD2); tr->dao = (bf16_t*)take(MD2); tr->dqkv = (bf16_t*)take((size_t)M * Nqkv * 2);
@@ -439,6 +458,7 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     const int rowsA = std::max(std::max(m->Fout, Nqkv), std::max(mlp, std::max(D, bott)));
     const int rowsB = std::max(std::max(m->Kp, mlp), std::max(D, bott));
     tr->tA = (bf16_t*)take((size_t)rowsA * Mpad * 2); tr->tB = (bf16_t*)take((size_t)rowsB * Mpad * 2);
+    tr->colsum_part = (float*)take((size_t)colsum_slices(M) * rowsA * 4);
     if (pass == 0) {
       tr->blob_bytes = o;
       if (hipMalloc((void**)&tr->blob, o) != hipSuccess) {

@@ -138,6 +138,47 @@ def test_gemm(variant, M, N, K, epi):
         assert rel(out, r) < 2e-6
 
 
+@pytest.mark.parametrize("tokens,out,inn,ksplit", [
+    (64, 128, 128, 1), (1, 128, 128, 1), (100, 128, 256, 1), (1000, 384, 256, 1), (1000, 384, 256, 4),
+    (2583, 256, 640, 3), (9660, 1280, 1280, 4), (9660, 5120, 1280, 1), (6182, 1280, 5120, 2),
+    # 256 x 256 tiles (out * in >= 2^20): automatic split, ragged and < 64-token batches, one K-tile per slice
+    (9660, 1280, 1280, 0), (9660, 3840, 1280, 0), (2583, 1024, 1024, 0), (37, 1024, 1024, 1), (4096, 1024, 1280, 7),
+    (130, 1024, 1024, 3), (9660, 5120, 1280, 0)])
+def test_weight_grad(tokens, out, inn, ksplit):
+    """dW = dY^T X and db = column sums of dY straight from the token-major operands (gemm_tn.hip): ragged token counts
+    (last K-tile zero-filled in LDS), split-K summed in order, no transposed copies.  The buffers are allocated exactly
+    `tokens` rows long inside a poisoned arena: whatever follows them must not leak into the sums."""
+    arena_y = torch.full(((tokens + 64) * out,), float("nan"), device=dev()).to(OP)
+    arena_x = torch.full(((tokens + 64) * inn,), float("nan"), device=dev()).to(OP)
+    dY = arena_y[:tokens * out].view(tokens, out)
+    X = arena_x[:tokens * inn].view(tokens, inn)
+    dY.copy_(gen((tokens, out), 40, 0.05).to(OP))
+    X.copy_((gen((tokens, inn), 41) + 0.25).to(OP))
+    dW = torch.full((out, inn), float("nan"), device=dev())
+    db = torch.full((out,), float("nan"), device=dev())
+    work = torch.full((64 + 16 * out * inn + 32 * out,), float("nan"), device=dev())
+    L.check(L.lib().jat_k_weight_grad(L.ptr(dY), L.ptr(X), L.ptr(dW), L.ptr(db), tokens, out, inn, ksplit, L.ptr(work),
+                                      work.numel() * 4, L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = dY.double().T @ X.double()
+    assert rel(dW, ref) < 3e-6
+    assert (dW.double() - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+    rb = dY.double().sum(0)
+    assert (db.double() - rb).abs().max() < 2e-5 * max(1.0, float(rb.abs().max()))
+    # bit-reproducible: fixed-order partial sums, no atomics
+    dW2 = torch.empty_like(dW)
+    L.check(L.lib().jat_k_weight_grad(L.ptr(dY), L.ptr(X), L.ptr(dW2), None, tokens, out, inn, ksplit, L.ptr(work),
+                                      work.numel() * 4, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dW, dW2)
+
+
+def test_weight_grad_rejects_unsupported_shapes():
+    z = torch.zeros((64, 192), device=dev()).to(OP)
+    o = torch.zeros((192, 192), device=dev())
+    assert L.lib().jat_k_weight_grad(L.ptr(z), L.ptr(z), L.ptr(o), None, 64, 192, 192, 1, None, 0, L.stream_ptr()) != 0
+
+
 def test_retired_gemm_variants_are_rejected():
     A = torch.zeros(128, 64, dtype=OP, device=dev())
     out = torch.zeros(128, 128, device=dev())
