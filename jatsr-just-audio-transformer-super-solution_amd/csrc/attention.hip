@@ -151,21 +151,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
           sum += pv;
         }
       if (p.drop.thresh) {   // training: dropout on the normalised probabilities = mask the numerators, keep the row sum
-        const int qi = min(q0 + qt * 16 + frow, N - 1);
-        const int64_t qrow = (((int64_t)b * p.Hq + h) * N + qi) * N;
+        const int64_t qrow = (((int64_t)b * p.Hq + h) * N + min(q0 + qt * 16 + frow, N - 1)) * N;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-          unsigned bits = 0;   // the lane's 8 consecutive keys key0 + 32 kk + 8 fg .. + 7: one byte of the row's keep mask
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int key = key0 + 32 * kk + 8 * fg + e;
-            const bool keep = jat_drop_keep(p.drop, (uint64_t)(qrow + key));
-            st[qt][2 * kk + (e >> 2)][e & 3] *= keep ? p.drop.inv_keep : 0.0f;
-            bits |= (keep ? 1u : 0u) << e;
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
+            st[qt][kt][r] *= jat_drop_mult(p.drop, (uint64_t)(qrow + key));
           }
-          if (p.dmask && q0 + qt * 16 + frow < N)
-            p.dmask[(((int64_t)b * p.Hq + h) * N + qi) * (p.npad >> 3) + (key0 >> 3) + 4 * kk + fg] = (unsigned char)bits;
-        }
       }
       l_run[qt] = l_run[qt] * alpha + sum;
       if (kb > 0) {

@@ -89,10 +89,6 @@ struct AttnArgs {
   float scale_log2e; // (1/sqrt(64)) * log2(e)
   float* lse;        // optional [B, Hq, N] fp32: log2-domain log-sum-exp per query row (training forward), else nullptr
   DropSpec drop;     // training: dropout on the attention probabilities (thresh == 0: off); element ((b*Hq+h)*N + q)*N + key
-  // optional (training, drop.thresh != 0): the keep bits of this call's dropout mask, [B*Hq*N rows][npad/8 bytes], bit
-  // (key & 7) of byte key/8 - the two backward kernels read them back instead of re-hashing every element (the two 32-bit
-  // multiplies of the hash are quarter rate: a third of the attention forward's time with dropout on)
-  unsigned char* dmask;
   const int* lens;   // optional [B] (device): sample b attends to keys < lens[b] only (a short chunk padded into a batch of
                      // longer ones, infer_test_v3m2.py:370-398: the reference runs it alone, unpadded); nullptr: all N keys
 };
@@ -167,8 +163,7 @@ hipError_t launch_norm_bwd(const float* x, const bf16_t* dy, const float* w, con
                            int64_t dmod_bstride, float* dw, int B, int D, int ntok, int mode, hipStream_t s);
 hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
                                 const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
-                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, const unsigned char* dmask, float* dkv_part,
-                                hipStream_t s);
+                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, float* dkv_part, hipStream_t s);
 hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
                            float loss_scale, hipStream_t s);
 // v3mod2 loss (MSE + lw * (fw*freq + mw*ms + cw*cons)): dpred = d(loss * loss_scale)/d pred, out6 = {total, mse, freq, ms,

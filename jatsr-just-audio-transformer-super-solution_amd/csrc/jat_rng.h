@@ -20,17 +20,13 @@ static inline uint32_t jat_hash32(uint32_t x) {   // "lowbias32" integer finalis
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-static inline bool jat_drop_keep(const DropSpec d, uint64_t idx) {
+static inline float jat_drop_mult(const DropSpec d, uint64_t idx) {
   // one finaliser round per element (two quarter-rate 32-bit multiplies): the site keys enter before (k0, together with
   // the rotated high half of the index) and after (k1) the mixing
   const uint32_t hi = (uint32_t)(idx >> 32);
   const uint32_t r = jat_hash32((uint32_t)idx ^ d.k0 ^ ((hi << 13) | (hi >> 19))) ^ d.k1;
-  return r >= d.thresh;
+  return r < d.thresh ? 0.0f : d.inv_keep;
 }
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-static inline float jat_drop_mult(const DropSpec d, uint64_t idx) { return jat_drop_keep(d, idx) ? d.inv_keep : 0.0f; }
 // site = layer * 8 + kind;  kind: 0 attention probabilities, 1 DropPath(attention branch), 2 MLP after GELU,
 // 3 MLP output, 4 DropPath(MLP branch)
 static inline DropSpec jat_drop_spec(uint64_t seed, uint32_t site, float p) {

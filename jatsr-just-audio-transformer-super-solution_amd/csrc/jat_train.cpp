@@ -24,7 +24,6 @@ namespace {
 struct TLayer {
   float *x_mid, *lse;
   bf16_t *xn1, *q, *k, *vt, *ao, *y_attn, *xn2, *h_pre, *h_post, *y_mlp;
-  unsigned char* dmask;   // keep bits of the attention-probability dropout, written by the forward, read by the backward
   bf16_t *wqkvT, *woT, *w1T, *w2T;
   // gradient / master-parameter offsets (floats) into the flat buffers
   int64_t o_n1, o_n2, o_q, o_k, o_v, o_o, o_w1, o_b1, o_w2, o_b2, o_ada_w, o_ada_b;
@@ -67,7 +66,6 @@ struct jat_trainer {
   float* dw_split = nullptr;           // split-K partials of the small dW GEMMs
   const void* zero_cell = nullptr;     // 256 zero bytes (the workspace is zeroed once and this cell is never written)
   float* colsum_part = nullptr;        // row-slice partials of the bias-gradient column sums
-  bool drop_mask = true;               // attention dropout: the forward stores the keep bits (JAT_DROP_MASK=0: the backward re-hashes)
   bool tn_dw = true;                   // dW straight from token-major operands (JAT_TN_DW=0: transposed copies + gemm_bf16_kernel)
   float* dkv_part = nullptr;           // per-query-head fp32 partials of dK / dV (attention backward)
   int64_t split4_area = 0, split2_area = 0;
@@ -203,7 +201,6 @@ int forward_train(jat_trainer* tr, const float* z_t, const float* t, const float
       a.scale_log2e = 0.125f * 1.4426950408889634f;
       a.lse = L.lse;
       a.drop = site(tr, l, 0);
-      a.dmask = a.drop.thresh ? L.dmask : nullptr;
       KCHK(launch_attention(a, s));
     }
     {
@@ -274,7 +271,7 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
     JCHK(input_grad(tr, tr->dy, D, L.woT, D, tr->dao, s));
     JCHK(weight_grad(tr, tr->dy, D, L.ao, D, G + L.o_o, nullptr, s));
     KCHK(launch_attention_bwd(L.q, L.k, L.vt, L.ao, tr->dao, L.lse, tr->delta, tr->dqkv, m->rope_cos, m->rope_sin, B, ntok,
-                              m->Hq, m->Hkv, tr->npad, site(tr, l, 0), L.dmask, tr->dkv_part, s));
+                              m->Hq, m->Hkv, tr->npad, site(tr, l, 0), tr->dkv_part, s));
     JCHK(input_grad(tr, tr->dqkv, Nqkv, L.wqkvT, D, tr->dxn, s));
     JCHK(weight_grad(tr, tr->dqkv, Nqkv, L.xn1, D, tr->dwqkv, nullptr, s));
     KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, s));
@@ -395,7 +392,6 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
   if (rc != JAT_OK) { delete tr; return rc; }
 
   if (const char* e = getenv("JAT_TN_DW")) tr->tn_dw = atoi(e) != 0;
-  if (const char* e = getenv("JAT_DROP_MASK")) tr->drop_mask = atoi(e) != 0;
   // ---- one allocation: transposed weights, saved activations, backward scratch ----
   for (int pass = 0; pass < 2; ++pass) {
     size_t o = 0;
@@ -408,7 +404,6 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
       TLayer& L = tr->L[l];
       L.x_mid = (float*)take(MD4);
       L.lse = (float*)take((size_t)B * m->Hq * ntok * 4);
-      L.dmask = tr->drop_mask ? (unsigned char*)take((size_t)B * m->Hq * ntok * (tr->npad / 8)) : nullptr;
       L.xn1 = (bf16_t*)take(MD2); L.q = (bf16_t*)take(MD2); L.k = (bf16_t*)take((size_t)M * kvD * 2);
       L.vt = (bf16_t*)take((size_t)B * m->Hkv * HEAD_DIM * tr->npad * 2);
       L.ao = (bf16_t*)take(MD2); L.y_attn = (bf16_t*)take(MD2); L.xn2 = (bf16_t*)take(MD2);

@@ -416,7 +416,6 @@ struct AttnBwdArgs {
   int B, N, Hq, Hkv, npad, D, kvD;
   float scale_log2e, scale;
   DropSpec drop;   // attention-probability dropout (:175): element ((b*Hq + h)*N + i)*N + j
-  const unsigned char* dmask;   // optional: the forward's keep bits [B*Hq*N][npad/8] (AttnArgs.dmask); nullptr: re-hash
   // dK/dV: the G query heads of a KV group may be spread over `hsplit` blocks (more, shorter blocks: better balance);
   // each then writes an fp32 partial [(b*Hkv + g)*hsplit + part][N][128] (dK | dV) summed by attn_dkv_reduce_kernel
   float* dkv_part;
@@ -577,14 +576,11 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkv_kernel(const AttnBwdArgs 
       tile_store(rq, sQ, tid);
       tile_store(rdo, sDO, tid);
       float l2[4], de[4];
-      unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};   // keep bits of keys j0 .. j0 + 63 of my four query rows
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wave * 16 + fg * 4 + r;
         l2[r] = i < N ? lse[i] : 0.f;
         de[r] = i < N ? dl[i] : 0.f;
-        if (p.drop.thresh && p.dmask)
-          mk[r] = *(const unsigned long long*)(p.dmask + (((int64_t)b * p.Hq + h) * N + min(i, N - 1)) * (p.npad >> 3) + (j0 >> 3));
       }
       __syncthreads();
       if (it + 1 < niter) {   // next (head, query block): global loads fly under this iteration's MFMAs
@@ -606,8 +602,7 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkv_kernel(const AttnBwdArgs 
           float dp = pacc[nt][r];
           if (p.drop.thresh) {   // O = (P o m) V:  dV uses P o m,  dP = (dO V^T) o m,  delta = rowsum(dO o O) unchanged
             const int64_t i = i0 + wave * 16 + fg * 4 + r, j = j0 + nt * 16 + fr;
-            const float mm = p.dmask ? (((mk[r] >> (nt * 16 + fr)) & 1ull) ? p.drop.inv_keep : 0.0f)
-                                     : jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
+            const float mm = jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
             dp *= mm;
             ds[r] = pr[r] * (dp - de[r]) * p.scale;
             pr[r] *= mm;
@@ -688,13 +683,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
   const float* lse = p.lse + ((int64_t)b * p.Hq + h) * N;
   const float* dl = p.delta + ((int64_t)b * p.Hq + h) * N;
   float l2[4], de[4];   // per query column i = i0 + 16 nt + fr of the transposed tiles
-  const unsigned char* mrow[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const int i = i0 + nt * 16 + fr;
     l2[nt] = i < N ? lse[i] : 0.f;
     de[nt] = i < N ? dl[i] : 0.f;
-    mrow[nt] = p.dmask ? p.dmask + (((int64_t)b * p.Hq + h) * N + min(i, N - 1)) * (p.npad >> 3) : nullptr;
   }
   f32x4_t dq[4];
 #pragma unroll
@@ -713,11 +706,6 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
       rk = tile_load(kb, p.ldk, j0 + 64, N, tid);
       rv = tile_load(vb + j0 + 64, p.npad, 0, 64, tid);
     }
-    unsigned mk[4] = {0u, 0u, 0u, 0u};   // keep bits of my keys j0 + 16 wave + 4 fg .. + 3 (a nibble) per query column
-    if (p.drop.thresh && p.dmask) {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) mk[nt] = mrow[nt][(j0 >> 3) + wave * 2 + (fg >> 1)] >> ((fg & 1) * 4);
-    }
     f32x4_t sacc[4], pacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) sacc[nt] = pacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -732,8 +720,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         float dp = pacc[nt][r];
         if (p.drop.thresh) {
           const int64_t i = i0 + nt * 16 + fr, j = j0 + wave * 16 + fg * 4 + r;
-          dp *= p.dmask ? (((mk[nt] >> r) & 1u) ? p.drop.inv_keep : 0.0f)
-                        : jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
+          dp *= jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
         }
         ds[r] = pr * (dp - de[nt]) * p.scale;
       }
@@ -772,12 +759,10 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 
 hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const bf16_t* o, const bf16_t* dout,
                                 const float* lse, float* delta, bf16_t* dqkv, const float* rope_cos, const float* rope_sin,
-                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, const unsigned char* dmask, float* dkv_part,
-                                hipStream_t s) {
+                                int B, int N, int Hq, int Hkv, int npad, DropSpec drop, float* dkv_part, hipStream_t s) {
   if (Hq % Hkv != 0 || npad % 64 != 0 || npad < N || N > 2048) return hipErrorInvalidValue;
   AttnBwdArgs a;
   a.drop = drop;
-  a.dmask = drop.thresh ? dmask : nullptr;
   a.q = q; a.k = k; a.vt = vt; a.dout = dout; a.lse = lse; a.delta = delta; a.dqkv = dqkv;
   a.rope_cos = rope_cos; a.rope_sin = rope_sin;
   a.D = Hq * 64; a.kvD = Hkv * 64; a.ldq = a.D; a.ldk = a.kvD; a.ldg = a.D + 2 * a.kvD;
