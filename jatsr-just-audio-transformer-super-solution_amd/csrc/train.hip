@@ -194,14 +194,16 @@ hipError_t launch_resid_gate(const float* x_in, const bf16_t* y, const float* ga
 // ---- backward of the gated residual: dy = bf16(dx * gate[b]);  dgate[b][n] = sum_tok dx * y -----------------------
 // grid (chunks of TOKC tokens, B); partial sums part[b][chunk][D]; finished by reduce_chunks_kernel.
 constexpr int TOKC = 16;
-__global__ void __launch_bounds__(256) gate_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ y,
+// blockDim = D/4 threads when that is at most 512 (D = 1280: 320 threads, one float4 column each: with 256 threads the second
+// pass over the columns ran a quarter full)
+__global__ void __launch_bounds__(512) gate_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ y,
                                                        const float* __restrict__ gate, int64_t gate_bstride,
                                                        bf16_t* __restrict__ dy, float* __restrict__ part, int D, int ntok,
                                                        const DropSpec path, const DropSpec elem) {
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int t0 = chunk * TOKC, t1 = min(t0 + TOKC, ntok);
   const float pm = path.thresh ? jat_drop_mult(path, (uint64_t)b) : 1.0f;
-  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
     f32x4_t g = *(const f32x4_t*)(gate + (int64_t)b * gate_bstride + c);
     g[0] *= pm; g[1] *= pm; g[2] *= pm; g[3] *= pm;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -250,7 +252,8 @@ hipError_t launch_gate_bwd(const float* dx, const bf16_t* y, const float* gate, 
                            float* part, float* dgate, int64_t dgate_bstride, int B, int D, int ntok, DropSpec path,
                            DropSpec elem, hipStream_t s) {
   const int nchunk = train_nchunk(ntok);
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(nchunk, B), dim3(256), 0, s, dx, y, gate, gate_bstride, dy, part, D, ntok, path,
+  const int nthr = (D / 4 <= 512 && D % 256 == 0) ? D / 4 : 256;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(nchunk, B), dim3(nthr), 0, s, dx, y, gate, gate_bstride, dy, part, D, ntok, path,
                      elem);
   hipLaunchKernelGGL(reduce_chunks_kernel, dim3((D + 255) / 256, B), dim3(256), 0, s, part, nchunk, (int64_t)D, dgate,
                      dgate_bstride, B, D, 0);
@@ -286,20 +289,33 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const float* __restrict__
       }
     }
   }
+  // the next row's loads (x, dy) are issued before the current row's three dependent wave
+  // reductions: a wave keeps two rows in flight (one row at a time left the kernel latency-bound at 55 us for 173 MB)
+  f32x4_t nx[NCH];
+  u32x2_t nd[NCH];
+  auto load_row = [&](int t) {
+    const int64_t row = (int64_t)b * ntok + t;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      nx[c] = *(const f32x4_t*)(x + row * D + c * 256 + lane * 4);
+      nd[c] = *(const u32x2_t*)(dy + row * D + c * 256 + lane * 4);
+    }
+  };
+  if (t0 + wave < t1) load_row(t0 + wave);
   for (int t = t0 + wave; t < t1; t += 4) {
     const int64_t row = (int64_t)b * ntok + t;
-    f32x4_t xv[NCH], gv[NCH], dv[NCH];
+    f32x4_t xv[NCH], gv[NCH], dv[NCH], old[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (c < nch) {
-        xv[c] = *(const f32x4_t*)(x + row * D + c * 256 + lane * 4);
-        const u32x2_t d2 = *(const u32x2_t*)(dy + row * D + c * 256 + lane * 4);
-        dv[c][0] = jat_lo2f(d2[0]); dv[c][1] = jat_hi2f(d2[0]);
-        dv[c][2] = jat_lo2f(d2[1]); dv[c][3] = jat_hi2f(d2[1]);
+    for (int c = 0; c < NCH; ++c) {
+      xv[c] = nx[c];
+      if (accumulate) old[c] = *(const f32x4_t*)(dx + row * D + c * 256 + lane * 4);   // needed last: flies under the reductions
+      dv[c][0] = jat_lo2f(nd[c][0]); dv[c][1] = jat_hi2f(nd[c][0]);
+      dv[c][2] = jat_lo2f(nd[c][1]); dv[c][3] = jat_hi2f(nd[c][1]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1 += xv[c][j]; s2 += xv[c][j] * xv[c][j]; }
-      }
+      for (int j = 0; j < 4; ++j) { s1 += xv[c][j]; s2 += xv[c][j] * xv[c][j]; }
+    }
+    if (t + 4 < t1) load_row(t + 4);
     float mu = 0.f, rstd;
     if (mode == 0) {
       rstd = rsqrtf(wave_sum_t(s2) / (float)D + 1e-6f);
@@ -308,41 +324,36 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const float* __restrict__
       float var = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
-        if (c < nch)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const float e = xv[c][j] - mu; var += e * e; }
+        for (int j = 0; j < 4; ++j) { const float e = xv[c][j] - mu; var += e * e; }
       rstd = rsqrtf(wave_sum_t(var) / (float)D + 1e-6f);
     }
     float mg = 0.f, mgx = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
-      if (c < nch)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float xh = (xv[c][j] - mu) * rstd;
-          const float g = dv[c][j] * ww[c][j] * sc1[c][j];
-          xv[c][j] = xh; gv[c][j] = g;
-          mg += g; mgx += g * xh;
-          a_sh[c][j] += dv[c][j];
-          a_sc[c][j] += dv[c][j] * xh * ww[c][j];
-          a_w[c][j] += dv[c][j] * sc1[c][j] * xh;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xv[c][j] - mu) * rstd;
+        const float g = dv[c][j] * ww[c][j] * sc1[c][j];
+        xv[c][j] = xh; gv[c][j] = g;
+        mg += g; mgx += g * xh;
+        a_sh[c][j] += dv[c][j];
+        a_sc[c][j] += dv[c][j] * xh * ww[c][j];
+        a_w[c][j] += dv[c][j] * sc1[c][j] * xh;
+      }
     mg = mode == 1 ? wave_sum_t(mg) / (float)D : 0.f;
     mgx = wave_sum_t(mgx) / (float)D;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (c < nch) {
-        f32x4_t o;
+    for (int c = 0; c < NCH; ++c) {
+      f32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[c][j] - mg - xv[c][j] * mgx);
-        float* dp = dx + row * D + c * 256 + lane * 4;
-        if (accumulate) {
-          const f32x4_t old = *(const f32x4_t*)dp;
+      for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[c][j] - mg - xv[c][j] * mgx);
+      if (accumulate) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += old[j];
-        }
-        *(f32x4_t*)dp = o;
+        for (int j = 0; j < 4; ++j) o[j] += old[c][j];
       }
+      *(f32x4_t*)(dx + row * D + c * 256 + lane * 4) = o;
+    }
   }
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
