@@ -126,19 +126,24 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
     bf16x8 pf[QT][NKK];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+      // max over the RAW scores (the scale is positive), keys past the end masked in the last key block only; the scale and
+      // the running maximum then enter one FMA per score: exp2(s * c - m)
       float mx = -1e30f;
+      if (key0 + KVB > Nb) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
+            if (key >= Nb) st[qt][kt][r] = -1e30f;
+          }
+      }
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
-          const float sv = key < Nb ? st[qt][kt][r] * p.scale_log2e : -1e30f;
-          st[qt][kt][r] = sv;
-          mx = fmaxf(mx, sv);
-        }
+        mx = fmaxf(mx, fmaxf(fmaxf(st[qt][kt][0], st[qt][kt][1]), fmaxf(st[qt][kt][2], st[qt][kt][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qt], mx);
+      const float m_new = fmaxf(m_run[qt], mx * p.scale_log2e);
       const float alpha = exp2f(m_run[qt] - m_new);
       m_run[qt] = m_new;
       float sum = 0.f;
@@ -146,19 +151,27 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f(st[qt][kt][r] - m_new);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(st[qt][kt][r], p.scale_log2e, -m_new));
           st[qt][kt][r] = pv;
           sum += pv;
         }
       if (p.drop.thresh) {   // training: dropout on the normalised probabilities = mask the numerators, keep the row sum
         const int64_t qrow = (((int64_t)b * p.Hq + h) * N + min(q0 + qt * 16 + frow, N - 1)) * N;
+        if ((uint64_t)p.B * p.Hq * N * N <= 0xffffffffull) {   // uniform: every element index of this call fits 32 bits
+          const uint32_t q32 = (uint32_t)qrow + key0 + 8 * fg;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
-            st[qt][kt][r] *= jat_drop_mult(p.drop, (uint64_t)(qrow + key));
-          }
+            for (int r = 0; r < 4; ++r) st[qt][kt][r] *= jat_drop_mult32(p.drop, q32 + 32 * (kt >> 1) + 4 * (kt & 1) + r);
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = key0 + 32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r;
+              st[qt][kt][r] *= jat_drop_mult(p.drop, (uint64_t)(qrow + key));
+            }
+        }
       }
       l_run[qt] = l_run[qt] * alpha + sum;
       if (kb > 0) {

@@ -27,6 +27,13 @@ static inline float jat_drop_mult(const DropSpec d, uint64_t idx) {
   const uint32_t r = jat_hash32((uint32_t)idx ^ d.k0 ^ ((hi << 13) | (hi >> 19))) ^ d.k1;
   return r < d.thresh ? 0.0f : d.inv_keep;
 }
+// the same draw for an element index known to fit 32 bits (hi = 0 above): no 64-bit index arithmetic per element
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline float jat_drop_mult32(const DropSpec d, uint32_t idx) {
+  return (jat_hash32(idx ^ d.k0) ^ d.k1) < d.thresh ? 0.0f : d.inv_keep;
+}
 // site = layer * 8 + kind;  kind: 0 attention probabilities, 1 DropPath(attention branch), 2 MLP after GELU,
 // 3 MLP output, 4 DropPath(MLP branch)
 static inline DropSpec jat_drop_spec(uint64_t seed, uint32_t site, float p) {

@@ -557,6 +557,7 @@ __device__ __forceinline__ void store_strip(const f32x4_t* acc, bf16_t* __restri
     }
 }
 
+template <bool IDX32>   // every dropout element index of the call fits 32 bits (B*Hq*N*N <= 2^32): no 64-bit index arithmetic per element
 __global__ void __launch_bounds__(256, 3) attn_bwd_dkv_kernel(const AttnBwdArgs p) {
   // K [j][d], V^T [d][j] (as stored), Q [i][d], dO [i][d] row-major; P^T, dS^T [j][i].  The products that contract over
   // the ROW index of an image (dP over d of V^T, dV / dK over i of dO / Q) read it with ds_read_b64_tr_b16.
@@ -609,11 +610,12 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkv_kernel(const AttnBwdArgs 
         float pr[4], ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pr[r] = exp2f(sacc[nt][r] * p.scale_log2e - l2[r]);
+          pr[r] = __builtin_amdgcn_exp2f(fmaf(sacc[nt][r], p.scale_log2e, -l2[r]));   // v_exp_f32 directly: no denormal-range fix-up ops
           float dp = pacc[nt][r];
           if (p.drop.thresh) {   // O = (P o m) V:  dV uses P o m,  dP = (dO V^T) o m,  delta = rowsum(dO o O) unchanged
             const int64_t i = i0 + wave * 16 + fg * 4 + r, j = j0 + nt * 16 + fr;
-            const float mm = jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
+            const float mm = IDX32 ? jat_drop_mult32(p.drop, (uint32_t)((b * p.Hq + h) * N + (int)i) * (uint32_t)N + (uint32_t)j)
+                                   : jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
             dp *= mm;
             ds[r] = pr[r] * (dp - de[r]) * p.scale;
             pr[r] *= mm;
@@ -684,6 +686,7 @@ __global__ void __launch_bounds__(256) attn_dkv_reduce_kernel(const AttnBwdArgs 
   }
 }
 
+template <bool IDX32>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned short sQ[64][AP], sDO[64][AP], sK[64][AP], sVt[64][AP], sDS[64][AP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
@@ -727,11 +730,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr = exp2f(sacc[nt][r] * p.scale_log2e - l2[nt]);
+        const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[nt][r], p.scale_log2e, -l2[nt]));
         float dp = pacc[nt][r];
         if (p.drop.thresh) {
           const int64_t i = i0 + nt * 16 + fr, j = j0 + wave * 16 + fg * 4 + r;
-          dp *= jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
+          dp *= IDX32 ? jat_drop_mult32(p.drop, (uint32_t)((b * p.Hq + h) * N + (int)i) * (uint32_t)N + (uint32_t)j)
+                      : jat_drop_mult(p.drop, (uint64_t)((((int64_t)b * p.Hq + h) * N + i) * N + j));
         }
         ds[r] = pr * (dp - de[nt]) * p.scale;
       }
@@ -785,12 +789,15 @@ hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* 
   // dkv_part (B*Hq*N*128 floats) given: one query head per block, partials reduced afterwards
   a.dkv_part = dkv_part;
   a.hsplit = (dkv_part && Hq > Hkv) ? Hq / Hkv : 1;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb, Hkv * a.hsplit, B), dim3(256), 0, s, a);
+  const bool idx32 = (uint64_t)B * Hq * N * N <= 0xffffffffull;
+  if (idx32) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(nb, Hkv * a.hsplit, B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(nb, Hkv * a.hsplit, B), dim3(256), 0, s, a);
   if (a.hsplit > 1) {
     const int64_t nr = (int64_t)B * Hkv * N * 64;
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s, a);
   }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb, Hq, B), dim3(256), 0, s, a);
+  if (idx32) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nb, Hq, B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nb, Hq, B), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
