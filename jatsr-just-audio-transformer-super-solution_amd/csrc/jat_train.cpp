@@ -457,7 +457,13 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     tr->dyf = (bf16_t*)take((size_t)M * m->Fout * 2);
     const int rowsA = std::max(std::max(m->Fout, Nqkv), std::max(mlp, std::max(D, bott)));
     const int rowsB = std::max(std::max(m->Kp, mlp), std::max(D, bott));
-    tr->tA = (bf16_t*)take((size_t)rowsA * Mpad * 2); tr->tB = (bf16_t*)take((size_t)rowsB * Mpad * 2);
+    {   // transposed activation copies: only for the weights gemm_tn.hip does not take (widths that are not multiples of 128)
+      const int shapes[][2] = {{m->Fout, D}, {D, mlp}, {mlp, D}, {D, D}, {Nqkv, D}, {D, bott}, {bott, m->Kp}};
+      bool need = !tr->tn_dw;
+      for (auto& sh : shapes) need = need || !gemm_tn_supports(sh[0], sh[1]);
+      tr->tA = need ? (bf16_t*)take((size_t)rowsA * Mpad * 2) : nullptr;
+      tr->tB = need ? (bf16_t*)take((size_t)rowsB * Mpad * 2) : nullptr;
+    }
     tr->colsum_part = (float*)take((size_t)colsum_slices(M) * rowsA * 4);
     if (pass == 0) {
       tr->blob_bytes = o;
