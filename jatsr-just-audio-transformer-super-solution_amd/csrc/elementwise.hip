@@ -153,10 +153,11 @@ hipError_t launch_norm_modulate(const float* x, const float* w, const float* shi
                                 int64_t mod_bstride, bf16_t* y, int M, int D, int ntok, int mode, hipStream_t s) {
   if (D % 256 != 0 || D > 2048 || M <= 0 || ntok <= 0) return hipErrorInvalidValue;
   if ((shift == nullptr) != (scale == nullptr)) return hipErrorInvalidValue;
-  // rows per wave: 4 amortise the weight loads and overlap a row's loads with the previous row's reduction, but a short batch
-  // (one chunk: M = 256) must still spread over the chip - one row per wave below 2048 rows (B = 1 run: 144 -> 129 ms)
+  // rows per wave: the persistent form (a wave walks rows w, w + nwaves, .. with the next row's loads in flight) was written for
+  // 4 rows per wave; measured, ONE row per wave is faster at every batch size (more waves in flight beat the amortised weight
+  // loads): 50-step run at M = 256: 144 -> 129.6 ms, M = 2760: 264.5 -> 255.2 ms, M = 7168 un-folded: 423 -> 418 ms
   static const int rpw_env = getenv("JAT_NORM_RPW") ? atoi(getenv("JAT_NORM_RPW")) : -1;
-  const int rows_per_wave = rpw_env >= 0 ? rpw_env : (M >= 8192 ? 4 : (M >= 2048 ? 2 : 1));
+  const int rows_per_wave = rpw_env >= 0 ? rpw_env : 1;
   if (rows_per_wave > 0 && (D == 1280 || D == 512 || D == 256)) {
     const int blocks = ((M + 3) / 4 + rows_per_wave - 1) / rows_per_wave;
     if (D == 1280)

@@ -40,6 +40,7 @@ struct Workspace {
 // Small-M inference (the reference's own B = 1 chunk loop gives M = 690 rows with CFG; a file's short last chunk M = 240):
 // the K = 5120 fc2 GEMM has a few dozen tiles x 80 K-steps — split K over otherwise idle CUs, finish in fixed order.
 static constexpr int kSplitMaxRows = 2304, kSplitMax = 8;
+static constexpr int kSplitWsRows = 4096;   // split-K partial workspace exists up to here (un-folded buckets: see resid_split)
 
 static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
   Workspace w;
@@ -68,7 +69,7 @@ static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
   w.t_emb = (float*)take((size_t)B * m->D * 4);
   w.t_silu = (bf16_t*)take((size_t)B * m->D * 2);
   w.part = (float*)take(M * 32 * 4);  // row partial sums of x^2 (norm folding), <= 32 wave column tiles
-  w.kpart = M <= kSplitMaxRows ? (float*)take((size_t)kSplitMax * M * m->D * 4) : nullptr;
+  w.kpart = M <= kSplitWsRows ? (float*)take((size_t)(M <= kSplitMaxRows ? kSplitMax : 2) * M * m->D * 4) : nullptr;
   w.total = off;
   return w;
 }
@@ -402,13 +403,19 @@ struct Fold {
 // K-slices for a gated-residual GEMM [M, D] = A[M, K] W^T whose tiles do not fill the chip (small-M inference), 1 = none
 static int resid_split(const jat_model* m, const Workspace& w, int site, int M, int K, bool folding) {
   if (!w.kpart || folding || K < 1024 || m->variants[site] >= 0) return 1;
-  int bm, bn;
-  const int v = pick_variant(M, m->D);
-  gemm_variant_tile(v, &bm, &bn);
-  const int tiles = ((M + bm - 1) / bm) * (m->D / bn), slots = (v == 18 || v == 20 || v == 27 || v == 28) ? 512 : 256;
-  int split = slots / tiles < kSplitMax ? slots / tiles : kSplitMax;
-  while (split > 1 && ((K / 64) % split != 0 || K / split < 256)) --split;   // >= 4 K-tiles per slice
-  return split > 1 ? split : 1;
+  auto slices = [&](int v, int cap) {
+    int bm, bn;
+    gemm_variant_tile(v, &bm, &bn);
+    const int tiles = ((M + bm - 1) / bm) * (m->D / bn), slots = (v == 18 || v == 20 || v == 27 || v == 28) ? 512 : 256;
+    int split = slots / tiles < cap ? slots / tiles : cap;
+    while (split > 1 && ((K / 64) % split != 0 || K / split < 256)) --split;   // >= 4 K-tiles per slice
+    return split > 1 ? split : 1;
+  };
+  if (M <= kSplitMaxRows) return slices(pick_variant(M, m->D), kSplitMax);
+  // a mid-size un-folded bucket (a T = 4096 file: M = 2760): the 64 x 128 tiles that fill the chip un-split are bound by the
+  // per-CU L2->LDS rate (24 KB per K-tile and block, two blocks per CU); for the long-K fc2 two slices of 128 x 128 tiles
+  // (the same 440 blocks, 2/3 of the bytes per flop) + the finishing pass are faster: 70 -> 45 us
+  return K >= 4096 ? slices(20, 2) : 1;
 }
 
 // one DiTBlock_GQA on the residual stream w.x  (jat_audiosr_v3.py:284-308); mod_l = this layer's 6D row of batch 0
