@@ -1425,6 +1425,7 @@ __global__ void __launch_bounds__(256) latent_loss_fft_kernel(const LatentLossAr
     const int step = (k1 * N2) % T;
     float pa = 0.f, pb = 0.f, ha = 0.f, hb = 0.f, ra = 0.f, rb = 0.f;
     int idx = 0;
+#pragma unroll 4
     for (int n1 = 0; n1 < N1; ++n1) {
       const float2 w = stw[idx];
       const int n = N2 * n1 + n2;
@@ -1448,6 +1449,7 @@ __global__ void __launch_bounds__(256) latent_loss_fft_kernel(const LatentLossAr
     const float2* yp = sY + k1 * N2;
     float pa = 0.f, pb = 0.f, ha = 0.f, hb = 0.f, ra = 0.f, rb = 0.f;
     int idx = 0;
+#pragma unroll 4
     for (int n2 = 0; n2 < N2; ++n2) {
       const float2 w = stw[idx];       // W^m = (cos, -sin): (yr + i yi)(c - i s) = (yr c + yi s) + i (yi c - yr s)
       float2 y = yp[n2];
@@ -1469,6 +1471,7 @@ __global__ void __launch_bounds__(256) latent_loss_fft_kernel(const LatentLossAr
     int idx = (k1 * n2) % T;
     const int step = (int)(((long long)N1 * n2) % T);
     float zr = 0.f, zi = 0.f;
+#pragma unroll 4
     for (int k = k1; k < F; k += N1) {
       const float2 w = stw[idx], g = sg[k];   // W^-m = (cos, +sin)
       zr += g.x * w.x - g.y * w.y;
@@ -1484,6 +1487,7 @@ __global__ void __launch_bounds__(256) latent_loss_fft_kernel(const LatentLossAr
     const int step = (N2 * n1) % T;
     float sv = 0.f;
     int idx = 0;
+#pragma unroll 4
     for (int k1 = 0; k1 < N1; ++k1) {
       const float2 w = stw[idx], z = sZ[k1 * N2 + n2];
       sv += z.x * w.x - z.y * w.y;
