@@ -509,6 +509,48 @@ __global__ void __launch_bounds__(256) splitk_resid_finish_kernel(const float* _
   for (int j = 0; j < 4; ++j) xv[j] += g[j] * (acc[j] + b[j]);
   *(f32x4_e*)(x + (int64_t)row * N + c) = xv;
 }
+// ---- finish of a split-K QKV GEMM (one chunk: M = 256, 56 tiles - five K-slices put 280 blocks on the weights): slice sum in
+// fixed order, RoPE on the pair-interleaved q / k features (gemm.hip EPI_QKV_ROPE: the pair (2d', 2d'+1) of a head holds
+// features d', d'+32), bf16 q / k rows and the transposed, key-padded V^T the attention kernels read.  One thread = 4 columns.
+__global__ void __launch_bounds__(256) splitk_qkv_finish_kernel(const float* __restrict__ part, int nsplit, int64_t stride,
+                                                                const float* __restrict__ rope_cos,
+                                                                const float* __restrict__ rope_sin, bf16_t* __restrict__ q,
+                                                                bf16_t* __restrict__ k, bf16_t* __restrict__ vt, int M, int D,
+                                                                int kvD, int ntok, int npad) {
+  const int Nq = D + 2 * kvD, per_row = Nq / 4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * per_row) return;
+  const int row = (int)(i / per_row), n = (int)(i % per_row) * 4;
+  f32x4_e acc = *(const f32x4_e*)(part + (int64_t)row * Nq + n);
+  for (int z = 1; z < nsplit; ++z) {
+    const f32x4_e v = *(const f32x4_e*)(part + (int64_t)z * stride + (int64_t)row * Nq + n);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  const int b = row / ntok, pos = row - b * ntok;
+  if (n < D + kvD) {
+    const int d0 = (n & 63) >> 1;
+    const float2 c = *(const float2*)(rope_cos + (int64_t)pos * 32 + d0);
+    const float2 sn = *(const float2*)(rope_sin + (int64_t)pos * 32 + d0);
+    const float o0 = __builtin_fmaf(acc[0], c.x, -(acc[1] * sn.x)), o1 = __builtin_fmaf(acc[1], c.x, acc[0] * sn.x);
+    const float o2 = __builtin_fmaf(acc[2], c.y, -(acc[3] * sn.y)), o3 = __builtin_fmaf(acc[3], c.y, acc[2] * sn.y);
+    bf16_t* dst = n < D ? q + (int64_t)row * D + n : k + (int64_t)row * kvD + (n - D);
+    *(uint2*)dst = pack4_e(o0, o1, o2, o3);
+  } else {
+    const int nv = n - D - kvD;   // 4 consecutive features of one V head (64 | 4)
+    bf16_t* dst = vt + ((int64_t)(b * (kvD >> 6) + (nv >> 6)) * 64 + (nv & 63)) * npad + pos;
+    const uint2 pk = pack4_e(acc[0], acc[1], acc[2], acc[3]);
+    dst[0] = (bf16_t)(pk.x & 0xffffu); dst[npad] = (bf16_t)(pk.x >> 16);
+    dst[2 * (int64_t)npad] = (bf16_t)(pk.y & 0xffffu); dst[3 * (int64_t)npad] = (bf16_t)(pk.y >> 16);
+  }
+}
+hipError_t launch_splitk_qkv_finish(const float* part, int nsplit, int64_t stride, const float* rope_cos, const float* rope_sin,
+                                    bf16_t* q, bf16_t* k, bf16_t* vt, int M, int D, int kvD, int ntok, int npad, hipStream_t s) {
+  if (D % 64 != 0 || kvD % 64 != 0 || nsplit < 1 || npad < ntok) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)M * ((D + 2 * kvD) / 4);
+  hipLaunchKernelGGL(splitk_qkv_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nsplit, stride, rope_cos,
+                     rope_sin, q, k, vt, M, D, kvD, ntok, npad);
+  return hipGetLastError();
+}
 hipError_t launch_splitk_resid_finish(const float* part, int nsplit, int64_t stride, const float* bias, const float* gate,
                                       int64_t gate_bstride, int ntok, float* x, int M, int N, hipStream_t s) {
   if (N % 4 != 0 || nsplit < 1) return hipErrorInvalidValue;

@@ -69,7 +69,7 @@ static Workspace carve(const jat_model* m, int B, int ntok, char* base) {
   w.t_emb = (float*)take((size_t)B * m->D * 4);
   w.t_silu = (bf16_t*)take((size_t)B * m->D * 2);
   w.part = (float*)take(M * 32 * 4);  // row partial sums of x^2 (norm folding), <= 32 wave column tiles
-  w.kpart = M <= kSplitWsRows ? (float*)take((size_t)(M <= kSplitMaxRows ? kSplitMax : 2) * M * m->D * 4) : nullptr;
+  w.kpart = M <= kSplitWsRows ? (float*)take((size_t)(M <= kSplitMaxRows ? kSplitMax : 2) * M * (m->D + 2 * m->kvD) * 4) : nullptr;   // widest user: the QKV GEMM
   w.total = off;
   return w;
 }
@@ -418,6 +418,22 @@ static int resid_split(const jat_model* m, const Workspace& w, int site, int M, 
   return K >= 4096 ? slices(20, 2) : 1;
 }
 
+// K-slices for the QKV GEMM of a small bucket (M <= kSplitMaxRows, un-folded, separate attention kernel): its 56 tiles at one
+// chunk leave 200 CUs without weights to pull; the slices are summed, rotated and laid out by splitk_qkv_finish_kernel
+static int qkv_split(const jat_model* m, const Workspace& w, int M, int K, bool folding) {
+  const char* on_s = getenv("JAT_QKV_SPLIT");   // read per call: tests A/B the two forms in one process
+  if ((on_s && atoi(on_s) == 0) || m->D % 64 != 0 || m->kvD % 64 != 0 || !w.kpart || folding || M > kSplitMaxRows || m->variants[G_QKV] >= 0) return 1;
+  const int N = m->D + 2 * m->kvD;
+  int bm, bn;
+  const int v = pick_variant(M, N);
+  gemm_variant_tile(v, &bm, &bn);
+  if (N % bn != 0) return 1;
+  const int tiles = ((M + bm - 1) / bm) * (N / bn), slots = (v == 18 || v == 20 || v == 27 || v == 28) ? 512 : 256;
+  int split = slots / tiles < kSplitMax ? slots / tiles : kSplitMax;
+  while (split > 1 && ((K / 64) % split != 0 || K / split < 256)) --split;
+  return split > 1 ? split : 1;
+}
+
 // one DiTBlock_GQA on the residual stream w.x  (jat_audiosr_v3.py:284-308); mod_l = this layer's 6D row of batch 0
 static int run_block(const jat_model* m, const Workspace& w, int l, int B, int ntok, const float* mod_l,
                      int64_t bstride, hipStream_t s, const Fold* f = nullptr) {
@@ -445,7 +461,16 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     e.out = w.q; e.k_out = w.k; e.vt_out = w.vt; e.D = D; e.kvD = m->kvD; e.npad = w.npad; e.ntok = ntok;
     e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin; e.rope_inv_freq = m->rope_invf;
     if (f) { e.rs_part = w.part; e.bias = f->bq_i + (int64_t)l * Nqkv; }
-    JCHK(gemm(m, G_QKV, w.xn, D, f ? f->wqkv_i + (int64_t)l * Nqkv * D : L.wqkv, D, M, Nqkv, D, EPI_QKV_ROPE, e, s));
+    const int qs = qkv_split(m, w, M, D, f != nullptr);
+    if (qs > 1) {
+      GemmArgs p{};
+      p.out = w.kpart; p.ldo = Nqkv; p.ntok = ntok; p.ksplit = qs; p.split_stride = (int64_t)M * Nqkv;
+      JCHK(gemm(m, G_QKV, w.xn, D, L.wqkv, D, M, Nqkv, D, EPI_F32, p, s));
+      KCHK(launch_splitk_qkv_finish(w.kpart, qs, (int64_t)M * Nqkv, m->rope_cos, m->rope_sin, w.q, w.k, w.vt, M, D, m->kvD, ntok,
+                                    w.npad, s));
+    } else {
+      JCHK(gemm(m, G_QKV, w.xn, D, f ? f->wqkv_i + (int64_t)l * Nqkv * D : L.wqkv, D, M, Nqkv, D, EPI_QKV_ROPE, e, s));
+    }
   }
   if (!fused_attn) {
     AttnArgs a{};

@@ -85,7 +85,12 @@ def test_fused_qkv_attention_is_bit_identical_to_separate_kernels(monkeypatch):
     monkeypatch.setenv("JAT_FUSE_QKV_ATTN", "2")    # 2 = force (the default only fuses when B*Hkv fills the GPU)
     fused = m(cuda(x_t), cuda(t), cuda(x_c))
     monkeypatch.setenv("JAT_FUSE_QKV_ATTN", "0")
+    monkeypatch.setenv("JAT_QKV_SPLIT", "0")        # the un-split QKV GEMM (a batch this small would split K: other summation order)
     separate = m(cuda(x_t), cuda(t), cuda(x_c))
+    monkeypatch.delenv("JAT_QKV_SPLIT")
+    split = m(cuda(x_t), cuda(t), cuda(x_c))         # the small-batch default: K-slices + splitk_qkv_finish_kernel
+    assert rel_l2(split.cpu().numpy(), separate.cpu().numpy()) < 2e-3
+    assert rel_l2(sub(split.cpu().numpy(), *meta["s_out"]), z["out64"]) < FWD_TOL
     if L.operand_dtype() == "bf16":
         assert torch.equal(fused, separate)
     else:
