@@ -551,6 +551,68 @@ hipError_t launch_splitk_qkv_finish(const float* part, int nsplit, int64_t strid
                      rope_sin, q, k, vt, M, D, kvD, ntok, npad);
   return hipGetLastError();
 }
+// The same finish FUSED with the norm + modulation that consumes the new residual row (norm2 of the block, norm1 of the next
+// block, or the final norm): one BLOCK per row, one float4 column per thread (D / 4 threads), the row statistics through a
+// fixed-order block reduction.  At one chunk (M = 256) a captured kernel node costs ~4 us whatever it does; this keeps the
+// wide, short shape of the finishing pass (a one-wave-per-row version with 40 dependent loads per lane was slower than the
+// two separate launches).
+__global__ void __launch_bounds__(512) splitk_resid_norm_block_kernel(const float* __restrict__ part, int nsplit, int64_t stride,
+                                                                      const float* __restrict__ bias, const float* __restrict__ gate,
+                                                                      int64_t gate_bstride, float* __restrict__ x,
+                                                                      const float* __restrict__ w, const float* __restrict__ shift,
+                                                                      const float* __restrict__ scale, int64_t mod_bstride,
+                                                                      bf16_t* __restrict__ y, int D, int ntok, int mode) {
+  __shared__ float red[2][8];
+  const int row = blockIdx.x, col = threadIdx.x * 4, b = row / ntok;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  f32x4_e acc = *(const f32x4_e*)(part + (int64_t)row * D + col);
+  for (int z = 1; z < nsplit; ++z) {
+    const f32x4_e v = *(const f32x4_e*)(part + (int64_t)z * stride + (int64_t)row * D + col);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  const f32x4_e bb = bias ? *(const f32x4_e*)(bias + col) : f32x4_e{0.f, 0.f, 0.f, 0.f};
+  const f32x4_e g = *(const f32x4_e*)(gate + (int64_t)b * gate_bstride + col);
+  f32x4_e xv = *(const f32x4_e*)(x + (int64_t)row * D + col);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xv[j] += g[j] * (acc[j] + bb[j]);
+  *(f32x4_e*)(x + (int64_t)row * D + col) = xv;
+  auto block_sum = [&](float v, int slot) {   // fixed order: lanes by shuffles, then the waves in index order
+    v = wave_sum(v);
+    if (lane == 0) red[slot][wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[slot][i];
+    return t;
+  };
+  float mu = 0.f, rstd = 1.f;
+  if (mode == 0) {
+    rstd = rsqrtf(block_sum(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3], 0) / (float)D + 1e-6f);
+  } else if (mode == 1) {
+    mu = block_sum(xv[0] + xv[1] + xv[2] + xv[3], 0) / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) var += (xv[e] - mu) * (xv[e] - mu);
+    rstd = rsqrtf(block_sum(var, 1) / (float)D + 1e-6f);
+  }
+  const f32x4_e ww = (mode == 0 && w) ? *(const f32x4_e*)(w + col) : f32x4_e{1.f, 1.f, 1.f, 1.f};
+  f32x4_e t = (xv - mu) * rstd * ww;
+  if (scale) {
+    const f32x4_e a = *(const f32x4_e*)(scale + (int64_t)b * mod_bstride + col);
+    const f32x4_e sft = *(const f32x4_e*)(shift + (int64_t)b * mod_bstride + col);
+    t = t * (1.f + a) + sft;
+  }
+  *(uint2*)(y + (int64_t)row * D + col) = pack4_e(t[0], t[1], t[2], t[3]);
+}
+// the fused form exists for widths of 256 .. 2048 in steps of 256 (D / 4 threads = whole waves, at most 8)
+bool splitk_resid_norm_supported(int D) { return D % 256 == 0 && D >= 256 && D <= 2048; }
+hipError_t launch_splitk_resid_norm(const float* part, int nsplit, int64_t stride, const float* bias, const float* gate,
+                                    int64_t gate_bstride, float* x, const float* w, const float* shift, const float* scale,
+                                    int64_t mod_bstride, bf16_t* y, int M, int D, int ntok, int mode, hipStream_t s) {
+  if (!splitk_resid_norm_supported(D) || nsplit < 1 || (shift == nullptr) != (scale == nullptr)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(splitk_resid_norm_block_kernel, dim3(M), dim3(D / 4), 0, s, part, nsplit, stride, bias, gate, gate_bstride, x, w,
+                     shift, scale, mod_bstride, y, D, ntok, mode);
+  return hipGetLastError();
+}
 hipError_t launch_splitk_resid_finish(const float* part, int nsplit, int64_t stride, const float* bias, const float* gate,
                                       int64_t gate_bstride, int ntok, float* x, int M, int N, hipStream_t s) {
   if (N % 4 != 0 || nsplit < 1) return hipErrorInvalidValue;

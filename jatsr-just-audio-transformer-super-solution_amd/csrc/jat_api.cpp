@@ -435,11 +435,18 @@ static int qkv_split(const jat_model* m, const Workspace& w, int M, int K, bool 
 }
 
 // one DiTBlock_GQA on the residual stream w.x  (jat_audiosr_v3.py:284-308); mod_l = this layer's 6D row of batch 0
+// The norm that consumes a block's output (norm1 of the next block, or the final norm: shift == nullptr) can ride in the
+// finishing pass of a split-K fc2 (small-M buckets): `next` describes it, *next_done reports that w.xn already holds it.
+struct NextNorm { const float *w, *shift, *scale; };
 static int run_block(const jat_model* m, const Workspace& w, int l, int B, int ntok, const float* mod_l,
-                     int64_t bstride, hipStream_t s, const Fold* f = nullptr) {
+                     int64_t bstride, hipStream_t s, const Fold* f = nullptr, bool xn_ready = false,
+                     const NextNorm* next = nullptr, bool* next_done = nullptr) {
   const int D = m->D, M = B * ntok, Nqkv = D + 2 * m->kvD;
   const LayerW& L = m->layers[l];
-  if (!f) KCHK(launch_norm_modulate(w.x, L.norm1, mod_l + 0 * D, mod_l + 1 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  if (next_done) *next_done = false;
+  const char* fuse_s2 = getenv("JAT_FUSE_FINISH");   // read per call: tests A/B the two forms in one process
+  const bool can_fuse = !(fuse_s2 && atoi(fuse_s2) == 0) && splitk_resid_norm_supported(D);
+  if (!f && !xn_ready) KCHK(launch_norm_modulate(w.x, L.norm1, mod_l + 0 * D, mod_l + 1 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   const char* fuse_s = getenv("JAT_FUSE_QKV_ATTN");  // read per call so that tests can A/B the two paths in one process
   const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
   // one block per (sample, KV group): worth it only when B * Hkv blocks fill the 256 CUs (measured: +1.8 % at
@@ -480,6 +487,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     a.lens = w.lens;
     KCHK(launch_attention(a, s));
   }
+  bool norm2_done = false;
   {
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
@@ -489,12 +497,18 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
       GemmArgs p{};
       p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D;
       JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_F32, p, s));
-      KCHK(launch_splitk_resid_finish(w.kpart, split, (int64_t)M * D, nullptr, mod_l + 2 * D, bstride, ntok, w.x, M, D, s));
+      if (can_fuse && !f) {   // slice sum + gate + residual + norm2 in one launch
+        KCHK(launch_splitk_resid_norm(w.kpart, split, (int64_t)M * D, nullptr, mod_l + 2 * D, bstride, w.x, L.norm2, mod_l + 3 * D,
+                                      mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+        norm2_done = true;
+      } else {
+        KCHK(launch_splitk_resid_finish(w.kpart, split, (int64_t)M * D, nullptr, mod_l + 2 * D, bstride, ntok, w.x, M, D, s));
+      }
     } else {
       JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_RESID, e, s));
     }
   }
-  if (!f) KCHK(launch_norm_modulate(w.x, L.norm2, mod_l + 3 * D, mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  if (!f && !norm2_done) KCHK(launch_norm_modulate(w.x, L.norm2, mod_l + 3 * D, mod_l + 4 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
     GemmArgs e{};
     e.out = w.hm; e.ldo = m->mlp; e.bias = L.b1; e.ntok = ntok;
@@ -510,7 +524,13 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
       GemmArgs p{};
       p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D;
       JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_F32, p, s));
-      KCHK(launch_splitk_resid_finish(w.kpart, split, (int64_t)M * D, L.b2, mod_l + 5 * D, bstride, ntok, w.x, M, D, s));
+      if (can_fuse && !f && next) {   // + the norm that reads this block's output
+        KCHK(launch_splitk_resid_norm(w.kpart, split, (int64_t)M * D, L.b2, mod_l + 5 * D, bstride, w.x, next->w, next->shift,
+                                      next->scale, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+        if (next_done) *next_done = true;
+      } else {
+        KCHK(launch_splitk_resid_finish(w.kpart, split, (int64_t)M * D, L.b2, mod_l + 5 * D, bstride, ntok, w.x, M, D, s));
+      }
     } else {
       JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_RESID, e, s));
     }
@@ -556,8 +576,16 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
     if (f) { e.fold_out = w.xn; e.fold_lo = w.xlo; e.fold_part = w.part; }
     JCHK(gemm(m, G_OTHER, w.h_patch, m->bott, m->pe_w2, m->bott, M, D, m->bott, EPI_F32, e, s));
   }
-  for (int l = 0; l < m->depth; ++l) JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s, f));
-  if (!f) KCHK(launch_norm_modulate(w.x, m->final_norm, nullptr, nullptr, 0, w.xn, M, D, ntok, m->cfg.norm_mode, s));
+  bool xn_ready = false;
+  for (int l = 0; l < m->depth; ++l) {
+    const float* mod_n = mod + (int64_t)(l + 1) * 6 * D;
+    const NextNorm nn = l + 1 < m->depth ? NextNorm{m->layers[l + 1].norm1, mod_n + 0 * D, mod_n + 1 * D}
+                                         : NextNorm{m->final_norm, nullptr, nullptr};
+    bool done = false;
+    JCHK(run_block(m, w, l, B, ntok, mod + (int64_t)l * 6 * D, mod_bstride, s, f, xn_ready, &nn, &done));
+    xn_ready = done;
+  }
+  if (!f && !xn_ready) KCHK(launch_norm_modulate(w.x, m->final_norm, nullptr, nullptr, 0, w.xn, M, D, ntok, m->cfg.norm_mode, s));
   {
     GemmArgs e{};
     e.out = x_pred; e.bias = m->bfinal; e.ntok = ntok; e.C_out = m->Cin; e.T_orig = T;

@@ -115,6 +115,11 @@ hipError_t launch_linear_f32(const float* in, const float* W, const float* bias,
 // finish of a split-K QKV GEMM: slice sum, RoPE, bf16 q / k rows and transposed V^T (what EPI_QKV_ROPE writes)
 hipError_t launch_splitk_qkv_finish(const float* part, int nsplit, int64_t stride, const float* rope_cos, const float* rope_sin,
                                     bf16_t* q, bf16_t* k, bf16_t* vt, int M, int D, int kvD, int ntok, int npad, hipStream_t s);
+// the same + the norm / modulation that consumes the updated rows (one launch instead of two)
+bool splitk_resid_norm_supported(int D);
+hipError_t launch_splitk_resid_norm(const float* part, int nsplit, int64_t stride, const float* bias, const float* gate,
+                                    int64_t gate_bstride, float* x, const float* w, const float* shift, const float* scale,
+                                    int64_t mod_bstride, bf16_t* y, int M, int D, int ntok, int mode, hipStream_t s);
 hipError_t launch_splitk_resid_finish(const float* part, int nsplit, int64_t stride, const float* bias, const float* gate,
                                       int64_t gate_bstride, int ntok, float* x, int M, int N, hipStream_t s);
 hipError_t launch_silu_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
