@@ -411,7 +411,11 @@ static int resid_split(const jat_model* m, const Workspace& w, int site, int M, 
     while (split > 1 && ((K / 64) % split != 0 || K / split < 256)) --split;   // >= 4 K-tiles per slice
     return split > 1 ? split : 1;
   };
-  if (M <= kSplitMaxRows) return slices(pick_variant(M, m->D), kSplitMax);
+  // Which tile the slices are cut for: 64 x 128 tiles (what pick_variant takes un-split) are bound by the per-CU L2->LDS rate
+  // (24 KB per K-tile and block, two blocks per CU); 128 x 128 tiles move 2/3 of the bytes per flop and, cut into more slices,
+  // give as many blocks.  Measured per 50-step run (B = 2 / 4 / 8): fc2 133.0 -> 130.3, 169.0 -> 154.5, 253.6 -> 220.1 ms (B = 1:
+  // neutral); out_proj only pays from M = 2048 (B = 8: 219.7 -> 212.8 ms).
+  if (M <= kSplitMaxRows) return slices((K >= 4096 || M >= 1536) ? 20 : pick_variant(M, m->D), kSplitMax);
   // a mid-size un-folded bucket (a T = 4096 file: M = 2760): the 64 x 128 tiles that fill the chip un-split are bound by the
   // per-CU L2->LDS rate (24 KB per K-tile and block, two blocks per CU); for the long-K fc2 two slices of 128 x 128 tiles
   // (the same 440 blocks, 2/3 of the bytes per flop) + the finishing pass are faster: 70 -> 45 us
