@@ -221,8 +221,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         uint2 r;
-        r.x = (unsigned)f2bf_a(o[qt][dt][0] * inv) | ((unsigned)f2bf_a(o[qt][dt][1] * inv) << 16);
-        r.y = (unsigned)f2bf_a(o[qt][dt][2] * inv) | ((unsigned)f2bf_a(o[qt][dt][3] * inv) << 16);
+        r.x = jat_pack2(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
+        r.y = jat_pack2(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
         *(uint2*)(op + dt * 16) = r;
       }
     }
@@ -358,8 +358,8 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           uint2 r;
-          r.x = (unsigned)f2bf_a(o[qt][dt][0] * inv) | ((unsigned)f2bf_a(o[qt][dt][1] * inv) << 16);
-          r.y = (unsigned)f2bf_a(o[qt][dt][2] * inv) | ((unsigned)f2bf_a(o[qt][dt][3] * inv) << 16);
+          r.x = jat_pack2(o[qt][dt][0] * inv, o[qt][dt][1] * inv);
+          r.y = jat_pack2(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
           *(uint2*)(op + dt * 16) = r;
         }
       }

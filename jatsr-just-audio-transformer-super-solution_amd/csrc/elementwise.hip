@@ -8,8 +8,8 @@
 __device__ __forceinline__ unsigned short f2bf_e(float f) { return jat_f2op(f); }
 __device__ __forceinline__ uint2 pack4_e(float a, float b, float c, float d) {
   uint2 r;
-  r.x = (unsigned)f2bf_e(a) | ((unsigned)f2bf_e(b) << 16);
-  r.y = (unsigned)f2bf_e(c) | ((unsigned)f2bf_e(d) << 16);
+  r.x = jat_pack2(a, b);
+  r.y = jat_pack2(c, d);
   return r;
 }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -35,8 +35,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ unsigned short f2bf(float f) { return jat_f2op(f); }
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   uint2 r;
-  r.x = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
-  r.y = (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16);
+  r.x = jat_pack2(a, b);
+  r.y = jat_pack2(c, d);
   return r;
 }
 // GELU (erf form, nn.GELU() default: jat_audiosr_v3.py:223,268) as x * Phi(x) with Phi(x) - 1/2 = x * Q(t), Q a degree-8
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
             const unsigned short ha = f2bf(x[2 * e]), hb = f2bf(x[2 * e + 1]);
             ho[e] = (unsigned)ha | ((unsigned)hb << 16);
             const float ra = x[2 * e] - jat_op2f(ha), rb = x[2 * e + 1] - jat_op2f(hb);
-            lw2[e] = (unsigned)f2bf(ra) | ((unsigned)f2bf(rb) << 16);
+            lw2[e] = jat_pack2(ra, rb);
             sq += x[2 * e] * x[2 * e] + x[2 * e + 1] * x[2 * e + 1];
           }
           const bool live = row < grows && m < p.M;

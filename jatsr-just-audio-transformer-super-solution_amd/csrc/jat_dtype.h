@@ -28,4 +28,14 @@ __device__ __forceinline__ float jat_lo2f(unsigned u) { return __builtin_bit_cas
 __device__ __forceinline__ float jat_hi2f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 #endif
 typedef __attribute__((ext_vector_type(8))) jat_op_t jat_opx8;
+// two fp32 -> one packed pair of operands (lo in bits 0..15).  fp16: v_cvt_pk_f16_f32 (round-to-nearest-even, one instruction
+// instead of two conversions and an OR); bf16: the scalar form, which the compiler already turns into v_cvt_pk_bf16_f32.
+#ifdef JAT_FP16
+__device__ __forceinline__ unsigned jat_pack2(float lo, float hi) {
+  typedef float jat_f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 jat_f16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(jat_f32x2{lo, hi}, jat_f16x2));
+}
+#else
 __device__ __forceinline__ unsigned jat_pack2(float lo, float hi) { return (unsigned)jat_f2op(lo) | ((unsigned)jat_f2op(hi) << 16); }
+#endif

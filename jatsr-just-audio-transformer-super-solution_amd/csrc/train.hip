@@ -30,7 +30,7 @@ __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
 __device__ __forceinline__ u32x4_t pack8(const float* f) {
   u32x4_t v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = (unsigned)f2bf_t(f[2 * i]) | ((unsigned)f2bf_t(f[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) v[i] = jat_pack2(f[2 * i], f[2 * i + 1]);
   return v;
 }
 
@@ -222,8 +222,8 @@ __global__ void __launch_bounds__(512) gate_bwd_kernel(const float* __restrict__
       e0 *= h0; e1 *= h1; e2 *= h2; e3 *= h3;
       acc[0] += d[0] * y0 * e0; acc[1] += d[1] * y1 * e1; acc[2] += d[2] * y2 * e2; acc[3] += d[3] * y3 * e3;
       u32x2_t o;
-      o[0] = (unsigned)f2bf_t(d[0] * g[0] * h0) | ((unsigned)f2bf_t(d[1] * g[1] * h1) << 16);
-      o[1] = (unsigned)f2bf_t(d[2] * g[2] * h2) | ((unsigned)f2bf_t(d[3] * g[3] * h3) << 16);
+      o[0] = jat_pack2(d[0] * g[0] * h0, d[1] * g[1] * h1);
+      o[1] = jat_pack2(d[2] * g[2] * h2, d[3] * g[3] * h3);
       *(u32x2_t*)(dy + row * D + c) = o;
     }
     *(f32x4_t*)(part + ((int64_t)b * nchunk + chunk) * D + c) = acc;
@@ -624,10 +624,10 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_dkv_kernel(const AttnBwdArgs 
           }
         }
         u32x2_t a, d;
-        a[0] = (unsigned)f2bf_t(pr[0]) | ((unsigned)f2bf_t(pr[1]) << 16);
-        a[1] = (unsigned)f2bf_t(pr[2]) | ((unsigned)f2bf_t(pr[3]) << 16);
-        d[0] = (unsigned)f2bf_t(ds[0]) | ((unsigned)f2bf_t(ds[1]) << 16);
-        d[1] = (unsigned)f2bf_t(ds[2]) | ((unsigned)f2bf_t(ds[3]) << 16);
+        a[0] = jat_pack2(pr[0], pr[1]);
+        a[1] = jat_pack2(pr[2], pr[3]);
+        d[0] = jat_pack2(ds[0], ds[1]);
+        d[1] = jat_pack2(ds[2], ds[3]);
         {
           const int row = nt * 16 + fr, col = wave * 16 + fg * 4;   // 8-byte store inside the swizzled 16-byte chunk
           const int sw = (((col >> 3) ^ (row & 7)) << 3) + (col & 7);
@@ -680,9 +680,9 @@ __global__ void __launch_bounds__(256) attn_dkv_reduce_kernel(const AttnBwdArgs 
   if (pr < 32) {   // dK pair (2d', 2d'+1): x0' = c x0 + s x1, x1' = c x1 - s x0
     const float c = p.rope_cos[min(j, 2047) * 32 + pr], sn = p.rope_sin[min(j, 2047) * 32 + pr];
     const float o0 = c * v0 + sn * v1, o1 = c * v1 - sn * v0;
-    *(unsigned*)(dst + g * 64 + pr * 2) = (unsigned)f2bf_t(o0) | ((unsigned)f2bf_t(o1) << 16);
+    *(unsigned*)(dst + g * 64 + pr * 2) = jat_pack2(o0, o1);
   } else {
-    *(unsigned*)(dst + p.kvD + g * 64 + (pr - 32) * 2) = (unsigned)f2bf_t(v0) | ((unsigned)f2bf_t(v1) << 16);
+    *(unsigned*)(dst + p.kvD + g * 64 + (pr - 32) * 2) = jat_pack2(v0, v1);
   }
 }
 
@@ -740,8 +740,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs p) {
         ds[r] = pr * (dp - de[nt]) * p.scale;
       }
       u32x2_t d;
-      d[0] = (unsigned)f2bf_t(ds[0]) | ((unsigned)f2bf_t(ds[1]) << 16);
-      d[1] = (unsigned)f2bf_t(ds[2]) | ((unsigned)f2bf_t(ds[3]) << 16);
+      d[0] = jat_pack2(ds[0], ds[1]);
+      d[1] = jat_pack2(ds[2], ds[3]);
       *(u32x2_t*)&sDS[nt * 16 + fr][wave * 16 + fg * 4] = d;   // dS[i][j]
     }
     __syncthreads();
