@@ -182,13 +182,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs p) {
       }
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        bf16x8 f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          f[r] = (jat_op_t)st[qt][2 * kk][r];
-          f[4 + r] = (jat_op_t)st[qt][2 * kk + 1][r];
-        }
-        pf[qt][kk] = f;
+        pf[qt][kk] = jat_pack8(st[qt][2 * kk], st[qt][2 * kk + 1]);
       }
     }
 
@@ -325,13 +319,7 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
       linv[qt] = 1.0f / sum;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        bf16x8 f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          f[r] = (jat_op_t)st[qt][2 * kk][r];
-          f[4 + r] = (jat_op_t)st[qt][2 * kk + 1][r];
-        }
-        pf[qt][kk] = f;
+        pf[qt][kk] = jat_pack8(st[qt][2 * kk], st[qt][2 * kk + 1]);
       }
     }
     f32x4 o[QT][4];

@@ -939,13 +939,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       inv[h] = 1.0f / sum;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f[e] = (jat_op_t)st[h][2 * kk][e];
-          f[4 + e] = (jat_op_t)st[h][2 * kk + 1][e];
-        }
-        pf[h][kk] = f;
+        pf[h][kk] = jat_pack8(st[h][2 * kk], st[h][2 * kk + 1]);
       }
     }
     f32x4 o[G][4];

@@ -39,3 +39,20 @@ __device__ __forceinline__ unsigned jat_pack2(float lo, float hi) {
 #else
 __device__ __forceinline__ unsigned jat_pack2(float lo, float hi) { return (unsigned)jat_f2op(lo) | ((unsigned)jat_f2op(hi) << 16); }
 #endif
+// eight fp32 (two accumulator quads) -> one MFMA operand fragment
+typedef float jat_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ jat_opx8 jat_pack8(const jat_f32x4 a, const jat_f32x4 b) {
+#ifdef JAT_FP16
+  typedef unsigned jat_u32x4 __attribute__((ext_vector_type(4)));
+  const jat_u32x4 u = {jat_pack2(a[0], a[1]), jat_pack2(a[2], a[3]), jat_pack2(b[0], b[1]), jat_pack2(b[2], b[3])};
+  return __builtin_bit_cast(jat_opx8, u);
+#else
+  jat_opx8 f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f[r] = (jat_op_t)a[r];
+    f[4 + r] = (jat_op_t)b[r];
+  }
+  return f;
+#endif
+}
