@@ -156,6 +156,10 @@ int jat_trainer_set_regularisers(jat_trainer* tr, const float* dropout, const fl
 int jat_trainer_set_latent_loss(jat_trainer* tr, double latent_weight, double freq_weight, double ms_weight,
                                 double consistency_weight, double low_freq_phase_ratio, double strict_cutoff,
                                 double soft_cutoff);
+/* Reconstruction loss of the V3M2-MOD1 trainer (train_ddp_v3m2mod1.py:72-101,150-151,666-672):
+ *   charbonnier_loss(pred, target, eps) = mean(sqrt((pred - target)^2 + eps)),  eps = 1e-6 (ADDED to the squared difference)
+ * eps > 0 selects it, eps == 0 returns to F.mse_loss.  Not combinable with the latent perceptual loss (JAT_E_STATE). */
+int jat_trainer_set_charbonnier(jat_trainer* tr, double eps);
 /* out6 (device): {total, mse, freq, ms, consistency, weighted latent sum} of the latest jat_trainer_fwd_bwd. */
 int jat_trainer_loss_terms(jat_trainer* tr, float* out6, void* stream);
 int jat_trainer_workspace_bytes(const jat_trainer* tr, size_t* out);
@@ -191,6 +195,19 @@ int jat_k_norm_modulate(const float* x, const float* w, const float* shift, cons
 int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N,
                int32_t K, int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch,
                int32_t variant, void* stream);
+/* The same GEMM with the sampler's norm folding (computes jat_audiosr_v3.py:297-306 for rows that share one
+ * modulation): the residual stream lives as two 16-bit planes x = hi + lo.
+ *   producer (hi != NULL; epilogue 0 or 3): x_new = acc + bias (0) | (hi + lo) + gate[b] * (acc + bias) (3), written back
+ *     as hi = round(x_new), lo = round(x_new - hi), plus part_out[M, N / jat_k_gemm_wave_n(variant)]: partial row sums of
+ *     x_new^2 in fixed order.  C is not touched.
+ *   consumer (part_in != NULL; any epilogue): accumulator row m scaled by rsqrt(sum_j part_in[m][j] / K + 1e-6) before the
+ *     bias; part_in_np in {4, 8, 16}.
+ * Variants with the coalesced epilogue only (>= 18). */
+int jat_k_gemm_fold(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K,
+                    int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch, uint16_t* hi,
+                    uint16_t* lo, float* part_out, const float* part_in, int32_t part_in_np, int32_t variant, void* stream);
+/* columns per wave tile of a GEMM tile variant (the slot width of part_out); 0 for an unknown variant */
+int jat_k_gemm_wave_n(int32_t variant);
 /* Weight gradient of y = x W^T + b from token-major operands: dW[out,in] = dY[tokens,out]^T X[tokens,in] (fp32), db[out] =
  * column sums of dY (db may be NULL).  out and in multiples of 128; ksplit >= 1 slices of the token axis summed in order
  * (0 = the count that fills the chip, at most 16); work: 256 + (ksplit > 1 ? ksplit*out*in*4 : 0) + 32*out*4 bytes.  (The backward of every nn.Linear of
@@ -207,6 +224,10 @@ int jat_k_latent_loss(const float* pred, const float* target, const float* lr, f
                       int32_t rows, int32_t T, double latent_weight, double freq_weight, double ms_weight,
                       double consistency_weight, double low_freq_phase_ratio, double strict_cutoff, double soft_cutoff,
                       float loss_scale, void* work, size_t work_bytes, void* stream);
+/* Reconstruction loss on n elements: eps == 0: F.mse_loss (train_ddp_v3m2.py:585), eps > 0: charbonnier_loss
+ * (train_ddp_v3m2mod1.py:72-101); dpred = d(loss * loss_scale)/d pred, loss_out: 1 float; work: >= 4104 bytes. */
+int jat_k_recon_loss(const float* pred, const float* target, float* dpred, float* loss_out, int64_t n, double eps,
+                     float loss_scale, void* work, size_t work_bytes, void* stream);
 /* fp32 -> bf16 (round-to-nearest-even) */
 int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 

@@ -55,8 +55,11 @@ SIGNATURES = {
     "jat_crossfade_pair": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _VP, _I32, _VP]),
     "jat_k_norm_modulate": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _I32, _I32, _I32, _VP]),
     "jat_k_gemm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _I64, _I32, _I32, _VP]),
+    "jat_k_gemm_fold": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _I64, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
+    "jat_k_gemm_wave_n": (C.c_int, [_I32]),
     "jat_k_weight_grad": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "jat_k_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "jat_k_recon_loss": (C.c_int, [_VP, _VP, _VP, _VP, _I64, C.c_double, _F32, _VP, _SZ, _VP]),
     "jat_k_cast_bf16": (C.c_int, [_VP, _VP, _I64, _VP]),
     "jat_k_latent_loss": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32] + [C.c_double] * 7 + [_F32, _VP, _SZ, _VP]),
     "jat_trainer_create": (C.c_int, [_VP, C.POINTER(JatTensorRef), _I32, _VP, _VP, _VP, _VP, _I64, _I32, _I32, _VP,
@@ -68,6 +71,7 @@ SIGNATURES = {
     "jat_trainer_set_grad_hook": (C.c_int, [_VP, _VP, _VP]),
     "jat_trainer_set_regularisers": (C.c_int, [_VP, C.POINTER(_F32), C.POINTER(_F32)]),
     "jat_trainer_set_latent_loss": (C.c_int, [_VP] + [C.c_double] * 7),
+    "jat_trainer_set_charbonnier": (C.c_int, [_VP, C.c_double]),
     "jat_trainer_loss_terms": (C.c_int, [_VP, _VP, _VP]),
     "jat_trainer_fwd_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F32, C.c_uint64, _VP, _VP, _VP]),
     "jat_trainer_optim": (C.c_int, [_VP, _F32, _F32, _F32, _F32, _F32, _F32, _F32, _I32, _VP, _VP]),
@@ -93,6 +97,8 @@ def lib():
                            f"g.build()'` or `make -C {os.path.dirname(LIB_PATH)}`); there is no CPU fallback")
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if not hasattr(h, name) and os.environ.get("JAT_LIB_ALLOW_MISSING"):
+                continue      # A/B against an OLDER build through JAT_LIB_PATH (tools/sampler_ab.py): it lacks the newest entry points
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args

@@ -28,9 +28,21 @@
 #include "jat_kernels.h"
 #include "jat_dtype.h"
 
+#include <type_traits>
+
 typedef jat_opx8 bf16x8;   // 8 operand elements (bf16, or fp16 in the -DJAT_FP16 build): one MFMA fragment
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return jat_f2op(f); }
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
@@ -39,35 +51,44 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   r.y = jat_pack2(c, d);
   return r;
 }
-// GELU (erf form, nn.GELU() default: jat_audiosr_v3.py:223,268) as x * Phi(x) with Phi(x) - 1/2 = x * Q(t), Q a degree-8
-// polynomial in t = 2 x^2 / 4.5^2 - 1 (weighted minimax fit of (Phi(x) - 1/2) / x on |x| <= 4.5; outside, x is clamped inside
-// Phi only: Phi(-4.5) = 3.4e-6).  |gelu_fast - gelu| <= 3.4e-5 for |x| <= 8 in fp32 (tests/test_host_cpu.py evaluates the
-// same expression in numpy against scipy's erf), i.e. 1/60 of the bf16 ulp the result is rounded to at |gelu| ~ 1.
-// No transcendental and every operation is a multiply-add: two elements per instruction (v_pk_fma_f32) — 7 VALU issues
-// per element instead of 20 for Abramowitz-Stegun 7.1.26 + exp + rcp.  The fc1 epilogue is VALU-bound (140 values per
-// lane per 224 x 320 tile): measured 24.6 us -> see profiles/r02/epilogue_cost.log.
+// GELU (erf form, nn.GELU() default: jat_audiosr_v3.py:223,268) as x * Phi(x), Phi(x) = clamp01(1/2 + x * Q(s)), s = clamp01(x^2 / 4.5^2),
+// Q a degree-8 polynomial (weighted minimax fit of (Phi(x) - 1/2) / x on |x| <= 4.5, monomial basis in s; beyond 4.5 the two
+// clamps saturate Phi at 0 / 1: Phi(-4.5) = 3.4e-6).  |gelu_fast - gelu| <= 6e-5 for all x in fp32 (tests/test_host_cpu.py
+// evaluates the same expression in numpy against scipy's erf), i.e. 1/30 of the half-ulp of the bf16 the result is rounded to at
+// |gelu| ~ 1.  No transcendental; the two clamps are the free output modifier of v_fma_f32 (hence scalar fmas there), everything
+// else packed fp32.  The fc1 epilogue is VALU-bound (140 values per lane per 224 x 320 tile), so what counts is (a) the issue
+// count: 13 fp32 multiply-add slots per element, and (b) that the chains of SEVERAL pairs are interleaved: one pair at a
+// time, every Horner step waits for the previous one (the compiler serialised the round-2 form: profiles/r03).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  const f32x2 xc = f32x2{__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
+template <int N>
+__device__ __forceinline__ void gelu_erf_n(f32x2 (&x)[N]) {
 #define JAT_C2(v) f32x2{v, v}
-  const f32x2 t = __builtin_elementwise_fma(xc * xc, JAT_C2(0.098765432f), JAT_C2(-1.0f));
-  f32x2 q = JAT_C2(0.0033544f);
-  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.00932879f));
-  q = __builtin_elementwise_fma(q, t, JAT_C2(0.01220736f));
-  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.01674371f));
-  q = __builtin_elementwise_fma(q, t, JAT_C2(0.02762998f));
-  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.04055589f));
-  q = __builtin_elementwise_fma(q, t, JAT_C2(0.05481848f));
-  q = __builtin_elementwise_fma(q, t, JAT_C2(-0.07717195f));
-  q = __builtin_elementwise_fma(q, t, JAT_C2(0.15690212f));
-  const f32x2 phi = __builtin_elementwise_fma(xc, q, JAT_C2(0.5f));
+  f32x2 s[N], q[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const f32x2 xs = x[i] * JAT_C2(0.22222222f);
+    s[i] = f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(xs[0], xs[0], 0.f), 0.f, 1.f),
+                 __builtin_amdgcn_fmed3f(__builtin_fmaf(xs[1], xs[1], 0.f), 0.f, 1.f)};
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(JAT_C2(0.858849732f), s[i], JAT_C2(-4.62950545f));
+  constexpr float cs[7] = {10.9725412f, -15.1604596f, 13.6928242f, -8.61624417f, 3.9305869f, -1.33619357f, 0.398712717f};
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], JAT_C2(cs[k]));
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const f32x2 phi = f32x2{__builtin_amdgcn_fmed3f(__builtin_fmaf(x[i][0], q[i][0], 0.5f), 0.f, 1.f),
+                            __builtin_amdgcn_fmed3f(__builtin_fmaf(x[i][1], q[i][1], 0.5f), 0.f, 1.f)};
+    x[i] = x[i] * phi;
+  }
 #undef JAT_C2
-  return x * phi;
 }
-__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
 __device__ __forceinline__ uint2 gelu_pack4(float a, float b, float c, float d) {
-  const f32x2 g0 = gelu_erf2(f32x2{a, b}), g1 = gelu_erf2(f32x2{c, d});
-  return pack4(g0[0], g0[1], g1[0], g1[1]);
+  f32x2 g[2] = {f32x2{a, b}, f32x2{c, d}};
+  gelu_erf_n<2>(g);
+  return pack4(g[0][0], g[0][1], g[1][0], g[1][1]);
 }
 
 // RoPE rotation of one pair (a, b) by the angle with cosine c and sine s, multiply-add contraction spelled out: left to
@@ -81,39 +102,57 @@ __device__ __forceinline__ float2 rope_rot(float a, float b, float c, float s) {
 // The partials of a wave tile's rows are one contiguous block of part[M][np]: read it lane-linear (16 B per lane, whole
 // cache lines) and finish the row sums with shuffles instead of gathering np floats per row (a 16-line gather per
 // instruction cost ~10 us per launch).  np in {4, 8, 16}; result: rstd[i] for row i*16 + (lane&15).
+// Three steps so that nothing of it sits on the kernel's critical path (round 2 ran it whole at kernel entry: 7 dependent L2
+// round trips + 63 ds_bpermute BEFORE the first operand DMA was issued, 5-6 us of a 47 us block: profiles/r03/timeline_*):
+//   issue   at kernel entry: the loads, as inline asm (the compiler would drain the operand DMA issued behind them at the
+//           first use of a compiler-visible load result: cdna_hip_programming.md "Pipelining across barriers");
+//   reduce  after the prologue DMA has been issued, behind a counted vmcnt: one value per load (in-lane sum + lane-group sum);
+//   finish  after the K loop: ONE shuffle per 16-row tile (the load that holds row r = 16 i + lane % 16 is (16 i) / rpi for
+//           every lane: r % 16 < 16 <= rpi) + rsqrt.
 template <int TM>
-__device__ __forceinline__ void rows_rstd(const GemmArgs& p, int row0, int lane, float (&rstd)[TM]) {
-#pragma unroll
-  for (int i = 0; i < TM; ++i) rstd[i] = 1.0f;
-  if (!p.rs_part) return;
-  const int lpr = p.rs_np >> 2;                    // lanes per row (1, 2 or 4)
-  const int rpi = 64 / lpr;                        // rows per 64-lane load
-  const int frow = lane & 15;
-  const float invk = 1.0f / (float)p.K;
-  float sums[TM];                                  // sums[t]: row sum held by the lpr lanes of row t*rpi + lane/lpr
+__device__ __forceinline__ void rows_rstd_issue(const GemmArgs& p, int row0, int lane, f32x4 (&rsv)[TM]) {
+  const int lg = p.rs_np >> 3;                     // log2 of the lanes per row (np 4 / 8 / 16 -> 1 / 2 / 4 lanes): 0, 1, 2
+  const int rpi = 64 >> lg;                        // rows per 64-lane load
+  // every one of the TM loads is issued, also those past the wave tile's rows when a load covers 32 or 64 rows (row clamped,
+  // value unused): a load under a condition would merge with a constant, and the compiler may copy an asm load's destination
+  // registers at such a merge BEFORE the data has landed (it counts them as written at the end of the asm statement)
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
-    sums[t] = 0.f;
-    if (t * rpi < TM * 16) {
-      const int row = min(row0 + t * rpi + lane / lpr, p.M - 1);
-      const float4 v = *(const float4*)(p.rs_part + (int64_t)row * p.rs_np + (lane % lpr) * 4);
-      float sq = (v.x + v.y) + (v.z + v.w);
-      if (lpr >= 2) sq += __shfl_xor(sq, 1);
-      if (lpr >= 4) sq += __shfl_xor(sq, 2);
-      sums[t] = sq;
-    }
+    const int row = min(row0 + t * rpi + (lane >> lg), p.M - 1);
+    const float* ptr = p.rs_part + (int64_t)row * p.rs_np + (lane & ((1 << lg) - 1)) * 4;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rsv[t]) : "v"(ptr) : "memory");
   }
+}
+// `younger`: vector-memory operations issued after rows_rstd_issue that may still be in flight (a compile-time count)
+template <int TM, int YOUNGER>
+__device__ __forceinline__ void rows_rstd_reduce(const GemmArgs& p, f32x4 (&rsv)[TM], float (&sums)[TM]) {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+#pragma unroll
+  for (int t = 0; t < TM; ++t) asm volatile("" : "+v"(rsv[t]));   // no use of a destination is scheduled above the wait
+  const int lpr = p.rs_np >> 2;
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {                   // sums[t]: row sum held by the lpr lanes of row t*rpi + lane/lpr
+    float sq = (rsv[t][0] + rsv[t][1]) + (rsv[t][2] + rsv[t][3]);
+    if (lpr >= 2) sq += __shfl_xor(sq, 1);
+    if (lpr >= 4) sq += __shfl_xor(sq, 2);
+    sums[t] = sq;
+  }
+}
+template <int TM>
+__device__ __forceinline__ void rows_rstd_finish(const GemmArgs& p, int lane, const float (&sums)[TM], float (&rstd)[TM]) {
+  const int lg = p.rs_np >> 3, rlog = 6 - lg, frow = lane & 15;   // lanes per row = 1 << lg, rows per load = 1 << rlog
+  const float invk = 1.0f / (float)p.K;
+  float sq[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int r = i * 16 + frow;                   // this lane's row inside the wave tile
-    float sq = 0.f;
+    const int ti = (i * 16) >> rlog;               // wave-uniform: which load holds the rows of tile i
+    float sel = sums[0];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {                 // static register index, wave-uniform select
-      const float cand = __shfl(sums[t], (r % rpi) * lpr);
-      if (r / rpi == t) sq = cand;
-    }
-    rstd[i] = rsqrtf(sq * invk + 1e-6f);
+    for (int t = 1; t < TM; ++t) sel = (t == ti) ? sums[t] : sel;   // static register index, uniform select
+    sq[i] = __shfl(sel, ((i * 16 + frow) & ((1 << rlog) - 1)) << lg);
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rstd[i] = rsqrtf(sq[i] * invk + 1e-6f);
 }
 // 4-wave blocks with <= 20 accumulator tiles per wave are meant to run two per CU (2 waves per SIMD): cap the
 // register allocation accordingly (2nd launch-bounds argument = waves per SIMD).
@@ -122,6 +161,37 @@ template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
 __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN == 4 && TM * TN <= 20) ? 2 : 1)
     gemm_bf16_kernel(const GemmArgs p_in) {
   GemmArgs p = p_in;
+  // whole-kernel timeline (-DJAT_TIMELINE diagnostic build only, tools/tl_probe.py): s_memtime at entry / K loop start / K loop
+  // end / after the epilogue's first barrier / exit, s_memrealtime at entry and exit; 8 words per wave, written at exit
+#ifdef JAT_TIMELINE
+  unsigned long long tl_[7] = {0, 0, 0, 0, 0, 0, 0};
+#define JAT_TL(i)                                                                          \
+  if (p.dbg_out) {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_[i])::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  }
+#define JAT_TLR(i)                                                                         \
+  if (p.dbg_out) {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_[i])::"memory");   \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  }
+#define JAT_TL_FLUSH()                                                                     \
+  {                                                                                        \
+    JAT_TL(4) JAT_TLR(6)                                                                   \
+    if (p.dbg_out && (threadIdx.x & 63) == 0) {                                            \
+      unsigned long long* o_ = p.dbg_out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8; \
+      for (int i_ = 0; i_ < 7; ++i_) o_[i_] = tl_[i_];                                     \
+      o_[7] = blockIdx.x;                                                                  \
+    }                                                                                      \
+  }
+  JAT_TL(0) JAT_TLR(5)
+#else
+#define JAT_TL(i)
+#define JAT_TLR(i)
+#define JAT_TL_FLUSH()
+#endif
   if (p.ksplit > 1) {   // split-K slice of this block (uniform): shift the operands along K and the output to its partial
     const int z = blockIdx.y;
     p.A += (int64_t)z * p.K;
@@ -216,8 +286,14 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
   };
 
   // norm folding, consumer side: 1/rms of this lane's TM rows, loaded before the K loop so the latency is hidden
-  float rstd_rows[TM];
-  rows_rstd<TM>(p, m0 + wm * TM * 16, lane, rstd_rows);
+  float rstd_rows[TM], rstd_sums[TM];
+  [[maybe_unused]] f32x4 rstd_raw[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rstd_rows[i] = 1.0f;
+  if (p.rs_part) {
+    rows_rstd_issue<TM>(p, m0 + wm * TM * 16, lane, rstd_raw);
+    if constexpr (PIPE != 8) rows_rstd_reduce<TM, 0>(p, rstd_raw, rstd_sums);   // PIPE 8: behind its prologue DMA, below
+  }
 
   const int nk = p.K / BK;
   if constexpr (PIPE == 6) {
@@ -434,12 +510,16 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
     dma_a0(0, 0); dma_b0(0, 0); dma_b1(0, 0); dma_a1(0, 0);
     if (nk > 1) {
       dma_a0(1, 1); dma_b0(1, 1); dma_b1(1, 1); dma_a1(1, 1);
+      if (p.rs_part) rows_rstd_reduce<TM, 2 * CTILE>(p, rstd_raw, rstd_sums);   // the row-statistic loads are older than both tiles
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTILE) : "memory");
     } else {
+      if (p.rs_part) rows_rstd_reduce<TM, CTILE>(p, rstd_raw, rstd_sums);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    static_assert(2 * CTILE <= 63, "vmcnt immediate");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
+    JAT_TL(1)
 #ifdef JAT_ABLATE   // timing ablations (wrong results; -DJAT_ABLATE builds only): dbg bit 1: no DMA after the prologue, bit 2: no fragment reads
     const bool abl_dma = p.dbg & 2, abl_rd = p.dbg & 4, abl_mma = p.dbg & 8;   // after K-tile 0, bit 3: no MFMAs
 #else
@@ -511,6 +591,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
 #undef JAT_Q
 #undef JAT_LOAD_END
 #undef JAT_MMA_END
+    JAT_TL(2)
     if (grp == 0) __builtin_amdgcn_s_barrier();
   } else {
     // interleave hint: one fragment read, then MPR MFMAs, ... (sched_group_barrier masks: MFMA 0x8, DS read 0x100)
@@ -549,6 +630,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
     }
   }
 
+  if (p.rs_part) rows_rstd_finish<TM>(p, lane, rstd_sums, rstd_rows);
   const int nw0 = n0 + wn * TN * 16;  // wave-uniform first column
 
   // ---- split-residual epilogue (sampler with folded norms).  The residual stream lives as TWO bf16 planes, x = hi + lo with
@@ -565,7 +647,8 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       constexpr int NCH8 = 32 * CPR8 / 64;     // chunks per lane per 32-row group (= TN)
       static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
       __builtin_amdgcn_s_barrier();            // every wave is done reading the staging buffers
-      if (p.dbg & 1) return;
+      JAT_TL(3)
+      if (p.dbg & 1) { JAT_TL_FLUSH() return; }
       char* wbuf = smem + wave * (32 * RS);
       const int mw0 = m0 + wm * TM * 16;
       float4 bb[TN];
@@ -615,8 +698,8 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
               float h0, h1, l0, l1;
               up(hw[e], h0, h1);
               up(lw[e], l0, l1);
-              x[2 * e] = (h0 + l0) + gg[2 * e] * x[2 * e];
-              x[2 * e + 1] = (h1 + l1) + gg[2 * e + 1] * x[2 * e + 1];
+              x[2 * e] = __builtin_fmaf(gg[2 * e], x[2 * e], h0 + l0);          // spelled out: left to -ffp-contract the two forms
+              x[2 * e + 1] = __builtin_fmaf(gg[2 * e + 1], x[2 * e + 1], h1 + l1);  // of this epilogue could round differently
             }
           }
           unsigned ho[4], lw2[4];
@@ -630,7 +713,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
             sq += x[2 * e] * x[2 * e] + x[2 * e + 1] * x[2 * e + 1];
           }
           const bool live = row < grows && m < p.M;
-          if (live) {
+          if (live && !(p.dbg & 128)) {
             *(uint4*)(p.fold_out + (int64_t)m * p.ldo + n) = uint4{ho[0], ho[1], ho[2], ho[3]};
             *(uint4*)(p.fold_lo + (int64_t)m * p.ldo + n) = uint4{lw2[0], lw2[1], lw2[2], lw2[3]};
           }
@@ -649,6 +732,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      JAT_TL_FLUSH()
       return;
     }
   }
@@ -666,7 +750,8 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
     constexpr int NCH = (32 * CPR + 63) / 64;  // chunks per lane per 32-row group
     static_assert(NW * 32 * RS <= 2 * STAGE, "epilogue slab does not fit the staging buffers");
     __builtin_amdgcn_s_barrier();             // every wave is done reading the staging buffers
-    if (p.dbg & 1) return;
+    JAT_TL(3)
+    if (p.dbg & 1) { JAT_TL_FLUSH() return; }
     char* wbuf = smem + wave * (32 * RS);
     const int mw0 = m0 + wm * TM * 16;
     float4 bb[TN];
@@ -674,6 +759,80 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
     for (int j = 0; j < TN; ++j)
       bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
     const int npass = (EPI == EPI_BF16_GELU && p.dual_rows > 0) ? 2 : 1;
+    // ---- software-pipelined form (CE == 2; bf16 / GELU outputs): the epilogue above runs per 32-row group as
+    //   [VALU: bias, GELU, pack -> slab] [slab -> 16-B global stores]
+    // and an in-order wave that meets a full store queue cannot start the next group's VALU: the vector work (GELU: 15
+    // multiply-adds per element) and the store drain add up instead of overlapping (profiles/r02/epilogue_cost.log: +11.6 us
+    // for the stores alone, +22.9 us with GELU).  Here the stores of group g-1 are issued ONE AT A TIME between the column
+    // tiles of group g's vector work (two slabs per wave, alternating), so the store path drains under the VALU of the same
+    // wave and of its SIMD partner.  Same arithmetic, same bytes, same addresses.
+    if constexpr (CE == 2 && (EPI == EPI_BF16_GELU || EPI == EPI_BF16)) {
+      if (npass == 1) {
+        constexpr int G = (TM + 1) / 2;
+        static_assert(NCH == TN && NW * 64 * RS <= 2 * STAGE, "pipelined epilogue: two slabs per wave, TN chunks per lane");
+        char* const slab0 = wbuf;
+        char* const slab1 = smem + (NW + wave) * (32 * RS);
+        int soff[NCH], goff[NCH], rowt[NCH];
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+          const int c = lane + 64 * t;
+          rowt[t] = c / CPR;
+          const int cc = c - rowt[t] * CPR;
+          soff[t] = rowt[t] * RS + cc * 16;
+          goff[t] = rowt[t] * (int)p.ldo * 2 + cc * 16;
+        }
+        u32x4 raw[NCH];
+        // compile-time group / tile indices throughout (static_for): a runtime index into acc / raw / slab would put them in scratch
+        auto vwrite = [&](auto gc, auto jc) __attribute__((always_inline)) {   // vector work of column tile j of group g -> slab[g & 1]
+          constexpr int g = decltype(gc)::value, j = decltype(jc)::value;
+          constexpr int NI = (2 * g + 1 < TM) ? 2 : 1;   // 16-row tiles in this group
+          f32x2 h[2 * NI];
+#pragma unroll
+          for (int ii = 0; ii < NI; ++ii) {
+            f32x4 v = acc[2 * g + ii][j] * rstd_rows[2 * g + ii];
+            h[2 * ii] = f32x2{v[0] + bb[j].x, v[1] + bb[j].y};
+            h[2 * ii + 1] = f32x2{v[2] + bb[j].z, v[3] + bb[j].w};
+          }
+          if constexpr (EPI == EPI_BF16_GELU) gelu_erf_n<2 * NI>(h);   // the chains of both tiles interleaved
+#pragma unroll
+          for (int ii = 0; ii < NI; ++ii)
+            *(uint2*)((g & 1 ? slab1 : slab0) + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 2) =
+                pack4(h[2 * ii][0], h[2 * ii][1], h[2 * ii + 1][0], h[2 * ii + 1][1]);
+        };
+        auto sread = [&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value;
+          static_for<0, NCH>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            raw[t] = *(const u32x4*)((g & 1 ? slab1 : slab0) + (rowt[t] < 32 ? soff[t] : 0));
+          });
+        };
+        auto gstore = [&](auto gc, auto tc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value, t = decltype(tc)::value;
+          constexpr int grows = (2 * g + 1 < TM) ? 32 : 16;
+          const int m = mw0 + g * 32 + rowt[t];
+          if (rowt[t] < grows && m < p.M && !(p.dbg & 128))
+            *(u32x4*)((char*)p.out + ((int64_t)(mw0 + g * 32) * p.ldo + nw0) * 2 + goff[t]) = raw[t];
+        };
+        static_for<0, TN>([&](auto jc) __attribute__((always_inline)) { vwrite(std::integral_constant<int, 0>{}, jc); });
+        static_for<1, G>([&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value;
+          // same-wave LDS accesses execute in order: the slab of group g-1 is complete, and slab[g & 1] (read in iteration g-1,
+          // consumed by its stores) is free to be rewritten
+          sread(std::integral_constant<int, g - 1>{});
+          static_for<0, TN>([&](auto jc) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            vwrite(gc, jc);
+            __builtin_amdgcn_sched_barrier(0);
+            gstore(std::integral_constant<int, g - 1>{}, jc);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        sread(std::integral_constant<int, G - 1>{});
+        static_for<0, NCH>([&](auto tc) __attribute__((always_inline)) { gstore(std::integral_constant<int, G - 1>{}, tc); });
+        JAT_TL_FLUSH()
+        return;
+      }
+    }
     for (int pass = 0; pass < npass; ++pass)
 #pragma unroll
     for (int ig = 0; ig < (TM + 1) / 2; ++ig) {
@@ -725,7 +884,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
         const int m = mw0 + ig * 32 + row, n = nw0 + cc * EPC;
         const uint4 raw = *(const uint4*)(wbuf + (row < 32 ? row : 0) * RS + cc * 16);
         if (row >= grows) continue;
-        if (m < p.M) {
+        if (m < p.M && !(p.dbg & 128)) {
           if constexpr (EPI == EPI_RESID) {
             float4 x;
             x.x = xs[tt][0] + gs[tt][0] * __uint_as_float(raw.x); x.y = xs[tt][1] + gs[tt][1] * __uint_as_float(raw.y);
@@ -741,6 +900,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    JAT_TL_FLUSH()
     return;
   }
 
@@ -1083,9 +1243,10 @@ static const int kVariantTile[][2] = {
     {0, 0}, {0, 0},                                  // 29-30: retired (PIPE 7)
     {224, 320}, {256, 160}, {256, 256}, {128, 448},  // 31-34: PIPE 8 (quadrant ping-pong, 2 LDS stages) + coalesced epilogue
     {224, 256},                                      // 35: PIPE 8
+    {224, 320},                                      // 36: the tile of 31 with the software-pipelined bf16 / GELU epilogue (CE == 2)
 };
 static const int kVariantWaveN[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32, 0, 0, 0, 0, 0, 0, 0,
-                                    80, 0, 64, 64, 0, 0, 0, 80, 64, 80, 64, 0, 0, 80, 80, 64, 112, 64};
+                                    80, 0, 64, 64, 0, 0, 0, 80, 64, 80, 64, 0, 0, 80, 80, 64, 112, 64, 80};
 int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
 bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
@@ -1120,6 +1281,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 33: return launch_epi<2, 4, 8, 4, 8, 1>(a, epi, s);
     case 34: return launch_epi<2, 4, 4, 7, 8, 1>(a, epi, s);
     case 35: return launch_epi<2, 4, 7, 4, 8, 1>(a, epi, s);
+    case 36: return launch_epi<2, 4, 7, 5, 8, 2>(a, epi, s);
   }
   return hipErrorInvalidValue;
 }

@@ -346,6 +346,9 @@ static int pick_variant(int M, int N, int nbatch = 1) {
     score *= (double)M / (double)(((M + c.bm - 1) / c.bm) * c.bm);
     if (score > best_score) { best_score = score; best = c.id; }
   }
+  // 36: the tile of 31 with the software-pipelined bf16 / GELU epilogue (JAT_EPI_PIPE=0 keeps the plain one: A/B)
+  static const int epi_pipe = getenv("JAT_EPI_PIPE") ? atoi(getenv("JAT_EPI_PIPE")) : 1;
+  if (epi_pipe && best == 31) best = 36;
   return best;
 }
 
@@ -1010,6 +1013,28 @@ extern "C" int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bia
   a.ntok = rows_per_batch > 0 ? rows_per_batch : 1;
   if (const char* d = getenv("JAT_GEMM_DBG")) a.dbg = atoi(d);
   if (const char* d = getenv("JAT_GEMM_TIMELINE")) a.dbg_out = (unsigned long long*)strtoull(d, nullptr, 0);  // tools/gemm_timeline.py
+  KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
+  return JAT_OK;
+}
+extern "C" int jat_k_gemm_wave_n(int32_t variant) { return gemm_variant_exists(variant) ? gemm_variant_wave_n(variant) : 0; }
+extern "C" int jat_k_gemm_fold(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K,
+                               int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch, uint16_t* hi,
+                               uint16_t* lo, float* part_out, const float* part_in, int32_t part_in_np, int32_t variant,
+                               void* stream) {
+  if (epilogue < 0 || epilogue > EPI_RESID) return fail(JAT_E_INVALID, "epilogue must be 0..3");
+  if (!gemm_variant_exists(variant) || !gemm_variant_coalesced(variant)) return fail(JAT_E_INVALID, "needs a coalesced-epilogue variant");
+  if (hi && (epilogue != EPI_F32 && epilogue != EPI_RESID)) return fail(JAT_E_INVALID, "producer epilogue must be 0 or 3");
+  if (hi && (!lo || !part_out)) return fail(JAT_E_INVALID, "producer needs hi, lo and part_out");
+  if (part_in && part_in_np != 4 && part_in_np != 8 && part_in_np != 16) return fail(JAT_E_INVALID, "part_in_np must be 4, 8 or 16");
+  GemmArgs a{};
+  a.A = A; a.W = W; a.lda = K; a.ldw = K; a.M = M; a.N = N; a.K = K;
+  a.out = C; a.ldo = N; a.bias = bias; a.gate = gate; a.gate_bstride = gate_bstride;
+  a.ntok = rows_per_batch > 0 ? rows_per_batch : 1;
+  a.fold_out = hi; a.fold_lo = lo; a.fold_part = part_out;
+  if (hi) a.fold_np = N / gemm_variant_wave_n(variant);
+  a.rs_part = part_in; a.rs_np = part_in_np;
+  if (const char* d = getenv("JAT_GEMM_DBG")) a.dbg = atoi(d);
+  if (const char* d = getenv("JAT_GEMM_TIMELINE")) a.dbg_out = (unsigned long long*)strtoull(d, nullptr, 0);  // tools/tl_probe.py
   KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
   return JAT_OK;
 }

@@ -29,7 +29,7 @@ __device__ __forceinline__ float jat_hi2f(unsigned u) { return __builtin_bit_cas
 #endif
 typedef __attribute__((ext_vector_type(8))) jat_op_t jat_opx8;
 // two fp32 -> one packed pair of operands (lo in bits 0..15).  fp16: v_cvt_pk_f16_f32 (round-to-nearest-even, one instruction
-// instead of two conversions and an OR); bf16: the scalar form, which the compiler already turns into v_cvt_pk_bf16_f32.
+// instead of two conversions and an OR); bf16: v_cvt_pk_bf16_f32 the same way.
 #ifdef JAT_FP16
 __device__ __forceinline__ unsigned jat_pack2(float lo, float hi) {
   typedef float jat_f32x2 __attribute__((ext_vector_type(2)));
@@ -37,7 +37,11 @@ __device__ __forceinline__ unsigned jat_pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(jat_f32x2{lo, hi}, jat_f16x2));
 }
 #else
-__device__ __forceinline__ unsigned jat_pack2(float lo, float hi) { return (unsigned)jat_f2op(lo) | ((unsigned)jat_f2op(hi) << 16); }
+__device__ __forceinline__ unsigned jat_pack2(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (the scalar form costs two + fix-ups)
+  typedef float jat_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 jat_bf16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(jat_f32x2{lo, hi}, jat_bf16x2));
+}
 #endif
 // eight fp32 (two accumulator quads) -> one MFMA operand fragment
 typedef float jat_f32x4 __attribute__((ext_vector_type(4)));

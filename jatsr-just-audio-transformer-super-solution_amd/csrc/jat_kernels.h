@@ -174,6 +174,10 @@ hipError_t launch_attention_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* 
                                 int B, int N, int Hq, int Hkv, int npad, DropSpec drop, float* dkv_part, hipStream_t s);
 hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
                            float loss_scale, hipStream_t s);
+// Charbonnier loss mean(sqrt((pred - target)^2 + eps)) (train_ddp_v3m2mod1.py:72-101) and d(loss * loss_scale)/d pred;
+// part: train_red_blocks() floats, loss2[0] = loss
+hipError_t launch_charbonnier_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
+                                   float eps, float loss_scale, hipStream_t s);
 // v3mod2 loss (MSE + lw * (fw*freq + mw*ms + cw*cons)): dpred = d(loss * loss_scale)/d pred, out6 = {total, mse, freq, ms,
 // cons, fw*freq + mw*ms + cw*cons}; part: rows*8 floats; tw: [T] (cos, sin)(2 pi m / T); lr may be null when cw == 0.
 // low / strict / soft band edges (in rfft bins) are computed by the caller exactly as the reference does (int(F * ratio)).

@@ -61,6 +61,7 @@ struct jat_trainer {
   float* dw_part = nullptr;
   // v3mod2 latent perceptual loss (jat_trainer_set_latent_loss); lw == 0: plain MSE (the V3 trainer)
   double lw = 0.0, fw = 0.5, mw = 0.5, cw = 0.1, phase_ratio = 0.3, strict_cut = 0.30, soft_cut = 0.36;
+  double charb_eps = 0.0;              // > 0: Charbonnier reconstruction loss (train_ddp_v3m2mod1.py:72-101) instead of MSE
   float2* tw = nullptr;                // [T] twiddles
   float *ll_part = nullptr, *terms = nullptr;
   float* dw_split = nullptr;           // split-K partials of the small dW GEMMs
@@ -241,6 +242,9 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
                             (float)tr->lw, (float)tr->fw, (float)tr->mw, (float)tr->cw, (int)((double)F * tr->phase_ratio),
                             (int)((double)F * tr->strict_cut), (int)((double)F * tr->soft_cut), loss_scale, s));
     HIPCHK(hipMemcpyAsync(tr->scal, tr->terms, 4, hipMemcpyDeviceToDevice, s));
+  } else if (tr->charb_eps > 0.0) {
+    KCHK(launch_charbonnier_grad(tr->pred, target, tr->dpred, tr->red_part, tr->scal, (int64_t)B * m->Cin * T,
+                                 (float)tr->charb_eps, loss_scale, s));
   } else {
     KCHK(launch_mse_grad(tr->pred, target, tr->dpred, tr->red_part, tr->scal, (int64_t)B * m->Cin * T, loss_scale, s));
   }
@@ -540,8 +544,19 @@ extern "C" int jat_trainer_set_latent_loss(jat_trainer* tr, double latent_weight
   if (!(low_freq_phase_ratio >= 0 && low_freq_phase_ratio <= 1 && strict_cutoff >= 0 && soft_cutoff >= strict_cutoff &&
         soft_cutoff <= 1))
     return fail(JAT_E_INVALID, "band ratios must satisfy 0 <= strict <= soft <= 1 and 0 <= phase ratio <= 1");
+  if (latent_weight != 0.0 && tr->charb_eps > 0.0)
+    return fail(JAT_E_STATE, "the latent perceptual loss is defined on top of the MSE loss only (train_ddp_v3mod2.py:889-896)");
   tr->lw = latent_weight; tr->fw = freq_weight; tr->mw = ms_weight; tr->cw = consistency_weight;
   tr->phase_ratio = low_freq_phase_ratio; tr->strict_cut = strict_cutoff; tr->soft_cut = soft_cutoff;
+  return JAT_OK;
+}
+
+extern "C" int jat_trainer_set_charbonnier(jat_trainer* tr, double eps) {
+  if (!tr) return fail(JAT_E_INVALID, "null argument");
+  if (!(eps >= 0.0)) return fail(JAT_E_INVALID, "eps must be >= 0 (0 selects the MSE loss)");
+  if (eps > 0.0 && tr->lw != 0.0)
+    return fail(JAT_E_STATE, "the latent perceptual loss is defined on top of the MSE loss only (train_ddp_v3mod2.py:889-896)");
+  tr->charb_eps = eps;
   return JAT_OK;
 }
 
@@ -600,6 +615,22 @@ extern "C" int jat_trainer_optim(jat_trainer* tr, float lr, float beta1, float b
                     eps, weight_decay, step, s));
   if (grad_norm_out) HIPCHK(hipMemcpyAsync(grad_norm_out, tr->scal + 3, 4, hipMemcpyDeviceToDevice, s));
   return repack(tr, s);
+}
+
+// per-kernel entry point (unit parity, validation): reconstruction loss and d(loss * loss_scale)/d pred on n elements;
+// eps > 0: Charbonnier (train_ddp_v3m2mod1.py:72-101), eps == 0: MSE (train_ddp_v3m2.py:585); work: 1024 floats
+extern "C" int jat_k_recon_loss(const float* pred, const float* target, float* dpred, float* loss_out, int64_t n, double eps,
+                                float loss_scale, void* work, size_t work_bytes, void* stream) {
+  if (!pred || !target || !dpred || !loss_out || !work || n <= 0 || !(eps >= 0.0)) return fail(JAT_E_INVALID, "bad argument");
+  const size_t need = ((size_t)train_red_blocks() + 2) * 4;
+  if (work_bytes < need) return fail(JAT_E_STATE, "work buffer too small: %zu < %zu bytes", work_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)work;
+  float* loss2 = part + train_red_blocks();
+  if (eps > 0.0) KCHK(launch_charbonnier_grad(pred, target, dpred, part, loss2, n, (float)eps, loss_scale, s));
+  else KCHK(launch_mse_grad(pred, target, dpred, part, loss2, n, loss_scale, s));
+  HIPCHK(hipMemcpyAsync(loss_out, loss2, 4, hipMemcpyDeviceToDevice, s));
+  return JAT_OK;
 }
 
 // per-kernel entry point (unit parity): the v3mod2 loss on [rows, T] tensors; `work` holds T*8 + rows*32 bytes

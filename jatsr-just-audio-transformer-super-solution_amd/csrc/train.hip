@@ -837,12 +837,53 @@ __global__ void __launch_bounds__(256) finish_sum_kernel(const float* __restrict
   }
   if (threadIdx.x == 0) { out[0] = (float)(red[0] * (double)scale); out[1] = (float)sqrt(red[0] * (double)scale); }
 }
+// ---- loss: Charbonnier, mean(sqrt((pred - target)^2 + eps)) (train_ddp_v3m2mod1.py:72-101: eps is ADDED to the squared
+// difference, not squared) and its gradient  dpred = (pred - target) / sqrt((pred - target)^2 + eps) / n * loss_scale.
+__global__ void __launch_bounds__(256) charbonnier_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                               float* __restrict__ dpred, float* __restrict__ part, int64_t n,
+                                                               float eps, float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const f32x4_t a = *(const f32x4_t*)(pred + i), t = *(const f32x4_t*)(target + i);
+      f32x4_t d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = a[j] - t[j], r = sqrtf(e * e + eps);
+        acc += r;
+        d[j] = e / r * gscale;
+      }
+      *(f32x4_t*)(dpred + i) = d;
+    } else {
+      for (int64_t k = i; k < n; ++k) {
+        const float e = pred[k] - target[k], r = sqrtf(e * e + eps);
+        acc += r;
+        dpred[k] = e / r * gscale;
+      }
+    }
+  }
+  acc = wave_sum_t(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 constexpr int RED_BLOCKS = 1024;
 int train_red_blocks() { return RED_BLOCKS; }
+hipError_t launch_charbonnier_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
+                                   float eps, float loss_scale, hipStream_t s);
 hipError_t launch_mse_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
                            float loss_scale, hipStream_t s) {
   hipLaunchKernelGGL(mse_grad_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, pred, target, dpred, part, n,
                      2.0f * loss_scale / (float)n);
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f / (float)n, loss2);
+  return hipGetLastError();
+}
+
+hipError_t launch_charbonnier_grad(const float* pred, const float* target, float* dpred, float* part, float* loss2, int64_t n,
+                                   float eps, float loss_scale, hipStream_t s) {
+  hipLaunchKernelGGL(charbonnier_grad_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, pred, target, dpred, part, n, eps,
+                     loss_scale / (float)n);
   hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, part, RED_BLOCKS, 1.0f / (float)n, loss2);
   return hipGetLastError();
 }

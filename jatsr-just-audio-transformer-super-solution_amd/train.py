@@ -119,10 +119,13 @@ class Trainer:
                  warmup_steps=1000, total_steps=None, use_grad_scaler=True, process_group=None, seed=None,
                  latent_loss_weight=0.0, freq_loss_weight=0.5, ms_loss_weight=0.5, consistency_weight=0.1,
                  low_freq_phase_ratio=0.3, strict_cutoff=0.30, soft_cutoff=0.36, overlap_grad_allreduce=True,
-                 distributed=True, amp_dtype=None):
+                 distributed=True, amp_dtype=None, loss="mse", charbonnier_eps=1e-6):
         """latent_loss_weight > 0 selects the v3mod2 trainer's loss, MSE + latent perceptual loss
         (train_ddp_v3mod2.py:53-321,362-372,889-896; its TrainConfig uses 0.3 with the other defaults given here, no CFG
         dropout and condition_noise_ratio 0.05); 0 is the MSE-only loss of train_ddp_v3m2.py:585.
+        loss: "mse" (F.mse_loss, train_ddp_v3m2.py:585) or "charbonnier" — the V3M2-MOD1 trainer's reconstruction loss
+        mean(sqrt((pred - target)^2 + charbonnier_eps)) (train_ddp_v3m2mod1.py:72-101, `use_charbonnier_loss` / `charbonnier_eps`
+        :150-151), used for the training step and for validation (:817-819); not combinable with the latent perceptual loss.
         distributed=False: never issue a collective even if a process group exists (a single rank timing a local step).
         amp_dtype: "bf16" (train_ddp_v3m2.py:545) or "fp16" (`torch.amp.autocast('cuda')` of train_ddp_v3mod2.py:854, with
         the dynamic loss scale of :745); must match the operand dtype of the loaded library, which is a process-level
@@ -198,7 +201,14 @@ class Trainer:
                                 ms_weight=float(ms_loss_weight), consistency_weight=float(consistency_weight),
                                 low_freq_phase_ratio=float(low_freq_phase_ratio), strict_cutoff=float(strict_cutoff),
                                 soft_cutoff=float(soft_cutoff))
+        if loss not in ("mse", "charbonnier"):
+            raise ValueError(f"loss must be 'mse' or 'charbonnier', got {loss!r}")
+        if loss == "charbonnier" and float(latent_loss_weight) != 0.0:
+            raise ValueError("the latent perceptual loss is defined on top of the MSE loss (train_ddp_v3mod2.py:889-896); "
+                             "the Charbonnier trainer (train_ddp_v3m2mod1.py) has no latent term")
+        self.loss, self.charbonnier_eps = loss, float(charbonnier_eps)
         L.check(L.lib().jat_trainer_set_latent_loss(self.ptr, *self.latent_loss.values()))
+        L.check(L.lib().jat_trainer_set_charbonnier(self.ptr, self.charbonnier_eps if loss == "charbonnier" else 0.0))
         self._terms = torch.zeros(6, dtype=torch.float32, device=dev)
         # gradient all-reduce overlapped with the backward: one async all-reduce per parameter slice as soon as its
         # last gradient kernel is enqueued (jat_trainer_set_grad_hook), on a side stream ordered by an event
@@ -389,8 +399,15 @@ class Trainer:
             z_t = tv * hr_norm + (1 - tv) * nz                          # plumbing-sized elementwise op, as in the reference
             pred = self.model(z_t.contiguous(), tt.contiguous(), lr_norm)
             rows = Bv * Cv
-            work = torch.empty((Tv * 8 + 255) // 256 * 256 + rows * 32, dtype=torch.uint8, device=self.device)
             scratch = torch.empty_like(pred)
+            if self.loss == "charbonnier":      # train_ddp_v3m2mod1.py:817-819: validation uses the training loss
+                work = torch.empty(4104, dtype=torch.uint8, device=self.device)
+                L.check(L.lib().jat_k_recon_loss(L.ptr(pred), L.ptr(hr_norm), L.ptr(scratch), L.ptr(out6), pred.numel(),
+                                                 self.charbonnier_eps, 1.0, L.ptr(work), work.numel(), L.stream_ptr()))
+                acc[0] += out6[0].double(); acc[1] += 1
+                losses.append(float(out6[0]))
+                continue
+            work = torch.empty((Tv * 8 + 255) // 256 * 256 + rows * 32, dtype=torch.uint8, device=self.device)
             L.check(L.lib().jat_k_latent_loss(L.ptr(pred), L.ptr(hr_norm), L.ptr(lr_norm), L.ptr(scratch), L.ptr(out6), rows, Tv,
                                               ll["latent_weight"], ll["freq_weight"], ll["ms_weight"], ll["consistency_weight"],
                                               ll["low_freq_phase_ratio"], ll["strict_cutoff"], ll["soft_cutoff"], 1.0,

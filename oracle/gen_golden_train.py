@@ -76,8 +76,43 @@ def step_inputs(cfg, B, T, salt):
     return hr, lr, noise
 
 
+def ref_charbonnier():
+    """`charbonnier_loss` of train_ddp_v3m2mod1.py:72-101, taken from the file itself with `ast` (the module cannot be
+    imported: tensorboard, process group)."""
+    src = open(os.path.join(REF, "train_ddp_v3m2mod1.py"), encoding="utf-8").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "charbonnier_loss"]
+    assert len(fn) == 1
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "train_ddp_v3m2mod1.py", "exec"), ns)
+    return ns["charbonnier_loss"]
+
+
+def charbonnier_case(name, B, C, T, salt=0, eps=1e-6):
+    """Value and d/d pred of the reference's charbonnier_loss (train_ddp_v3m2mod1.py:72-101,666-672) on recipe tensors; a third
+    of the elements have |pred - target| around sqrt(eps) or exactly 0, where the loss leaves its L1 regime."""
+    fn = ref_charbonnier()
+    pred_np = recipe.gaussian("charb_pred", (B, C, T), salt + 500)
+    target_np = recipe.gaussian("charb_target", (B, C, T), salt + 501)
+    near = recipe.gaussian("charb_near", (B, C, T), salt + 502)
+    flat_t, flat_p, flat_n = target_np.reshape(-1), pred_np.reshape(-1), near.reshape(-1)
+    flat_t[::3] = flat_p[::3] + 2e-3 * flat_n[::3]       # |d| ~ sqrt(eps) = 1e-3
+    flat_t[::9] = flat_p[::9]                            # d == 0: gradient exactly 0, loss sqrt(eps)
+    rec = {}
+    for tag, dt in (("64", torch.float64), ("32", torch.float32)):
+        pred = torch.from_numpy(pred_np).to(dt).requires_grad_(True)
+        loss = fn(pred, torch.from_numpy(target_np).to(dt), eps=eps)
+        loss.backward()
+        rec["loss" + tag] = np.float64(loss.item())
+        rec["dpred" + tag] = pred.grad.numpy()
+    rec["meta"] = json.dumps(dict(case=name, B=B, C=C, T=T, salt=salt, eps=eps, torch=torch.__version__))
+    np.savez_compressed(os.path.join(GOLD, f"train_charbonnier_{name}.npz"), **rec)
+    print(f"[golden] train_charbonnier_{name}: loss64={rec['loss64']:.8f} loss32-loss64={rec['loss32'] - rec['loss64']:.2e}")
+
+
 def train_case(name, cfg_name, B, T, t_list, mask_list, norm="rms", salt=0, lr_rate=5e-5, wd=0.1, clip=1.0,
-               strides=(7, 5)):
+               strides=(7, 5), loss_name="mse", charbonnier_eps=1e-6):
+    """loss_name: "mse" (train_ddp_v3m2.py:585) or "charbonnier" (the V3M2-MOD1 trainer, train_ddp_v3m2mod1.py:666-672)."""
+    charb = ref_charbonnier() if loss_name == "charbonnier" else None
     cfg = recipe.CONFIGS[cfg_name]
     hr, lr, noise = step_inputs(cfg, B, T, salt)
     t = np.asarray(t_list, dtype=np.float32)
@@ -94,7 +129,7 @@ def train_case(name, cfg_name, B, T, t_list, mask_list, norm="rms", salt=0, lr_r
         opt = torch.optim.AdamW(m.parameters(), lr=lr_rate, weight_decay=wd)
         before = {k: p.detach().clone() for k, p in m.named_parameters()}
         pred = m(z_t, tt, lr_in)
-        loss = torch.nn.functional.mse_loss(pred, hr_t)
+        loss = charb(pred, hr_t, eps=charbonnier_eps) if charb else torch.nn.functional.mse_loss(pred, hr_t)
         loss.backward()
         grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
         gnorm = torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
@@ -119,7 +154,8 @@ def train_case(name, cfg_name, B, T, t_list, mask_list, norm="rms", salt=0, lr_r
             rec["g32_norm_dev_max"] = np.float64(worst)
     rec["meta"] = json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, t=[float(v) for v in t],
                                   mask=[bool(v) for v in mask], norm=norm, salt=salt, lr=lr_rate, wd=wd, clip=clip,
-                                  full_limit=FULL_LIMIT, strides=strides, torch=torch.__version__,
+                                  full_limit=FULL_LIMIT, strides=strides, torch=torch.__version__, loss=loss_name,
+                                  charbonnier_eps=charbonnier_eps,
                                   names=[k for k, _ in ref_model(cfg, norm, salt, torch.float32).named_parameters()]))
     np.savez_compressed(os.path.join(GOLD, f"train_{name}.npz"), **rec)
     sz = os.path.getsize(os.path.join(GOLD, f"train_{name}.npz"))
@@ -344,6 +380,12 @@ def main(which):
     if "v3mod2" in which:   # full-size model: ~15 GB of host memory, a few minutes; not part of the default set
         big_case("v3mod2_T128", "v3mod2", 2, 128, [0.2, 0.9], [False, True])
         big_case("v3mod2_T70_ragged", "v3mod2", 2, 70, [0.35, 0.8], [False, False], salt=1)
+    if allc or "charbonnier" in which:    # the V3M2-MOD1 trainer's reconstruction loss (train_ddp_v3m2mod1.py:72-101)
+        charbonnier_case("T24", 2, 32, 24)
+        charbonnier_case("T1378", 1, 8, 1378, salt=1)
+        train_case("micro_charbonnier_T24", "micro", 2, 24, [0.1, 0.85], [False, True], salt=3, loss_name="charbonnier")
+        train_case("tiny_charbonnier_T128", "tiny", 2, 128, [0.2, 0.9], [False, True], salt=2, strides=(61, 53),
+                   loss_name="charbonnier")
     if allc or "misc" in which:
         u_shape_case()
 

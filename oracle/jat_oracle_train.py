@@ -242,10 +242,14 @@ class TrainOracle:
         return grads
 
     # ---- the step ---------------------------------------------------------------------------------------------------
-    def loss_and_grads(self, z_t, t, cond, target, plan=None, latent=None, cond_clean=None):
+    def loss_and_grads(self, z_t, t, cond, target, plan=None, latent=None, cond_clean=None, charbonnier_eps=None):
         """latent: None (MSE, train_ddp_v3m2.py:585) or the keyword dict of latent_loss_oracle.latent_loss (the v3mod2
-        loss, train_ddp_v3mod2.py:889-896, evaluated against the clean condition latent `cond_clean`)."""
+        loss, train_ddp_v3mod2.py:889-896, evaluated against the clean condition latent `cond_clean`);
+        charbonnier_eps: the V3M2-MOD1 reconstruction loss instead of MSE (train_ddp_v3m2mod1.py:72-101,666-672)."""
         pred = self.forward(z_t, t, cond, plan)
+        if charbonnier_eps is not None:
+            loss, dpred = charbonnier_loss(pred, target, charbonnier_eps)
+            return loss, self.backward(dpred), pred
         if latent:
             from . import latent_loss_oracle as LO
             terms, dpred = LO.latent_loss(pred, target, cond_clean, **latent)
@@ -269,6 +273,14 @@ class TrainOracle:
             state[k] = (m, v)
             out[k] = p * (1 - lr * weight_decay) - (lr / bc1) * m / (np.sqrt(v) / math.sqrt(bc2) + eps)
         return total, out, state
+
+
+def charbonnier_loss(pred, target, eps=1e-6):
+    """train_ddp_v3m2mod1.py:72-101: mean(sqrt((pred - target)^2 + eps)) — eps is added to the SQUARED difference — and its
+    gradient d / sqrt(d^2 + eps) / n.  Returns (loss, dpred) in fp64."""
+    d = np.asarray(pred, np.float64) - np.asarray(target, np.float64)
+    r = np.sqrt(d * d + eps)
+    return float(r.mean()), d / r / d.size
 
 
 def u_shaped_timestep_sampling(u, alpha=0.5):

@@ -95,7 +95,7 @@ GEMM_SHAPES = [(128, 128, 64), (256, 512, 128), (1000, 1792, 1280), (56, 1536, 2
 
 # every live tile / pipeline variant of gemm.hip (ids are stable; the structures measured and retired in rounds 1-2 are
 # rejected by launch_gemm: test_retired_gemm_variants_are_rejected); JAT_TEST_VARIANTS="31,32" narrows the sweep
-LIVE_VARIANTS = [10, 18, 20, 21, 25, 26, 27, 28, 31, 32, 33, 34, 35]
+LIVE_VARIANTS = [10, 18, 20, 21, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36]
 GEMM_VARIANTS = [int(v) for v in os.environ.get("JAT_TEST_VARIANTS", "").split(",") if v] or LIVE_VARIANTS
 
 
@@ -136,6 +136,76 @@ def test_gemm(variant, M, N, K, epi):
         bidx = torch.arange(M, device=A.device) // ntok
         r = x0.double() + gate.double()[bidx] * ref
         assert rel(out, r) < 2e-6
+
+
+def _fold_case(M, N, K, ntok, seed):
+    A, Af = bf16_bits(gen((M, K), seed))
+    W, Wf = bf16_bits(gen((N, K), seed + 1, 1.0 / np.sqrt(K)))
+    bias = gen((N,), seed + 2, 0.1)
+    B = (M + ntok - 1) // ntok
+    gate = gen((B, N), seed + 3, 0.5)
+    x0 = gen((M, N), seed + 4, 2.0)
+    hi0 = x0.to(OP)
+    lo0 = (x0 - hi0.float()).to(OP)
+    return A, Af, W, Wf, bias, gate, hi0, lo0
+
+
+@pytest.mark.parametrize("variant", [20, 25, 32])
+@pytest.mark.parametrize("M,N,K,ntok", [(300, 1280, 256, 128), (512, 1280, 128, 128), (300, 1280, 192, 23), (700, 1280, 64, 345)])
+@pytest.mark.parametrize("epi", [0, 3])
+def test_gemm_fold_producer(variant, M, N, K, ntok, epi):
+    """Split-residual epilogue of the sampler's folded norms (jat_k_gemm_fold): x_new = acc + bias (epilogue 0) or
+    (hi + lo) + gate (acc + bias) (epilogue 3, jat_audiosr_v3.py:300,306) kept as two 16-bit planes, plus the row partial
+    sums of x_new^2 the consumer's rstd is built from; ragged M, wave tiles inside one sample / across two / across many."""
+    A, Af, W, Wf, bias, gate, hi0, lo0 = _fold_case(M, N, K, ntok, 200 + epi)
+    if N % (L.lib().jat_k_gemm_wave_n(variant) or 1) != 0:
+        pytest.skip("tile does not divide N")
+    wn = L.lib().jat_k_gemm_wave_n(variant)
+    hi, lo = hi0.clone(), lo0.clone()
+    part = torch.full((M, N // wn), float("nan"), device=A.device)
+    L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), None, M, N, K, epi, L.ptr(gate), N, ntok, L.ptr(hi),
+                                    L.ptr(lo), L.ptr(part), None, 0, variant, L.stream_ptr()))
+    torch.cuda.synchronize()
+    y = Af.double() @ Wf.double().T + bias.double()
+    if epi == 3:
+        bidx = torch.arange(M, device=A.device) // ntok
+        ref = (hi0.double() + lo0.double()) + gate.double()[bidx] * y
+    else:
+        ref = y
+    got = hi.double() + lo.double()
+    # hi = round(x), lo = round(x - hi): 16 significant bits (bf16) / 22 (fp16)
+    assert (got - ref).abs().max() <= 2 ** -15 * float(ref.abs().max()) + 1e-6
+    # hi alone is x rounded to the operand dtype: it is the next GEMM's A operand as it stands
+    assert ((hi.double() - ref).abs() <= 2 ** -8 * ref.abs() + 1e-6).all()
+    assert rel(part.double().sum(1), (ref * ref).sum(1)) < 1e-5
+
+
+@pytest.mark.parametrize("variant", [31, 36])
+@pytest.mark.parametrize("np_", [4, 8, 16])
+@pytest.mark.parametrize("epi", [1, 2])
+def test_gemm_fold_consumer(variant, np_, epi):
+    """Consumer side: accumulator rows scaled by rsqrt(sum_j part[m][j] / K + 1e-6) before the bias (the RMSNorm statistic
+    of jat_audiosr_v3.py:297,303 applied after the matmul), bf16 / GELU outputs; 36 = 31 + pipelined epilogue, bit-identical."""
+    M, N, K, ntok = 500, 2240, 192, 128
+    A, Af = bf16_bits(gen((M, K), 220))
+    W, Wf = bf16_bits(gen((N, K), 221, 1.0 / np.sqrt(K)))
+    bias = gen((N,), 222, 0.1)
+    part = gen((M, np_), 223).abs() * K / np_ + 0.1
+    out = torch.zeros((M, N), dtype=OP, device=A.device)
+    L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(out), M, N, K, epi, None, 0, ntok, None, None, None,
+                                    L.ptr(part), np_, variant, L.stream_ptr()))
+    torch.cuda.synchronize()
+    rstd = torch.rsqrt(part.double().sum(1, keepdim=True) / K + 1e-6)
+    ref = rstd * (Af.double() @ Wf.double().T) + bias.double()
+    if epi == 2:
+        ref = torch.nn.functional.gelu(ref)
+    assert rel(out, ref) < 3e-3
+    if variant == 36:
+        out31 = torch.zeros_like(out)
+        L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(out31), M, N, K, epi, None, 0, ntok, None, None,
+                                        None, L.ptr(part), np_, 31, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, out31)
 
 
 @pytest.mark.parametrize("tokens,out,inn,ksplit", [

@@ -141,26 +141,30 @@ def test_chunk_plan_and_shard_range():
 
 
 def test_fast_gelu_expression_is_far_below_a_bf16_ulp():
-    """csrc/gemm.hip `gelu_erf2` evaluates nn.GELU() (erf form, jat_audiosr_v3.py:223,268) as x * (1/2 + xc * Q(t)),
-    t = 2 xc^2 / 4.5^2 - 1, xc = clamp(x, +-4.5), Q of degree 8 (no transcendental, packed fp32 multiply-adds); the same fp32
-    expression in numpy against scipy's erf: |error| <= 4e-5 for |x| <= 8 (the result is then rounded to bf16: half an ulp
-    is 2e-3 at |gelu| ~ 1); beyond the clamp the error is relative: <= 1.2e-5 |x| on either side."""
+    """csrc/gemm.hip `gelu_erf_n` evaluates nn.GELU() (erf form, jat_audiosr_v3.py:223,268) as x * clamp01(1/2 + x * Q(s)),
+    s = clamp01((x / 4.5)^2), Q of degree 8 in s (no transcendental; the clamps are free output modifiers); the same fp32
+    expression in numpy against scipy's erf: |error| <= 7e-5 for all x (the result is then rounded to bf16: half an ulp
+    is 2e-3 at |gelu| ~ 1); beyond 4.5 Phi saturates at exactly 0 / 1."""
     import numpy as np
     from scipy.special import erf
-    m = np.array([0.15690212, -0.07717195, 0.05481848, -0.04055589, 0.02762998, -0.01674371, 0.01220736, -0.00932879,
-                  0.0033544], np.float32)
+    m = np.array([0.398712717, -1.33619357, 3.9305869, -8.61624417, 13.6928242, -15.1604596, 10.9725412, -4.62950545,
+                  0.858849732], np.float32)
+
+    def fma(a, b, c):     # one rounding, like v_fma_f32
+        return (a.astype(np.float64) * b.astype(np.float64) + np.float64(c)).astype(np.float32)
 
     def gelu_fast(x):
         x = x.astype(np.float32)
-        xc = np.clip(x, -4.5, 4.5).astype(np.float32)
-        t = (xc * xc * np.float32(0.098765432) - np.float32(1)).astype(np.float32)
-        q = np.full_like(t, m[-1])
+        xs = (x * np.float32(0.22222222)).astype(np.float32)
+        s = np.clip(fma(xs, xs, 0.0), 0, 1).astype(np.float32)
+        q = np.full_like(s, m[-1])
         for k in range(len(m) - 2, -1, -1):
-            q = (q * t + m[k]).astype(np.float32)
-        return (x * (np.float32(0.5) + xc * q).astype(np.float32)).astype(np.float32)
+            q = fma(q, s, m[k])
+        phi = np.clip(fma(x, q, 0.5), 0, 1).astype(np.float32)
+        return (x * phi).astype(np.float32)
     x = np.linspace(-8, 8, 1_600_001).astype(np.float32)
     ref = x.astype(np.float64) * 0.5 * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
-    assert np.abs(gelu_fast(x) - ref).max() < 4e-5
+    assert np.abs(gelu_fast(x) - ref).max() < 7e-5
     big = np.array([10.0, 100.0, 1e4], np.float32)
     assert np.all(np.abs(gelu_fast(big) / big - 1) < 1.2e-5)
     assert np.all(np.abs(gelu_fast(-big)) < 1.2e-5 * big)
