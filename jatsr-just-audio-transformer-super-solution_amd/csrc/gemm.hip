@@ -1198,6 +1198,390 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
 }
 
 // -----------------------------------------------------------------------------------------------------
+// Persistent two-tile form of the quadrant ping-pong GEMM (PIPE 8 above, same K loop) for a CONSUMER GEMM with more tiles than
+// CUs: the MLP fc1 of the sampler, M = 7168, N = 5120 -> 512 tiles of 224 x 320 on 256 CUs.  As two rounds of one-tile blocks
+// (variant 36) every block pays, per tile (profiles/r03/timeline_*): ~5 us from entry to the first MFMA (cold first K-tiles,
+// 35 MB requested by 256 CUs at once), ~33 us of K loop, ~7 us of epilogue, and the second round starts 2-5 us after the first
+// exits.  Here ONE block per CU walks two tiles, and while it runs the first tile's epilogue the first K-tile of the second
+// tile (+ its bias slice and row statistics) is already streaming into LDS:
+//     [X0, K-tiles 0/1 of tile 0] K loop | read rstd / bias from LDS | barrier | DMA: X1, K-tile 0 of tile 1 -> stage 0 |
+//     epilogue of tile 0 (slabs in stage 1; its stores drain under the next K loop) | barrier | DMA: K-tile 1 -> stage 1 |
+//     counted vmcnt | K loop of tile 1 | epilogue
+// What makes the overlap work:
+//   * nothing the epilogue waits for is a vector-memory LOAD (vmcnt counts loads and stores in issue order: one compiler-
+//     inserted vmcnt(0) for a bias load would drain the prefetch first): the tile's bias slice and its rows of the producer's
+//     row partial sums arrive by LDS-DMA with the first K-tile ("X": 2 + 14 KiB beside the two stages) and are read with
+//     ds_read; the 28 registers of raw partials and the shuffles of the one-tile kernels are gone;
+//   * the epilogue issues EXACTLY NST stores per wave (M % BM == 0, whole tiles only), so "tile 1's first K-tile has landed"
+//     is the counted wait vmcnt(NST + CTILE) behind the DMA of its second K-tile: the stores stay in flight;
+//   * the epilogue works on 16-row groups (two 2.8 KB slabs per wave, alternating) with the stores of group g-1 issued between
+//     the column-tile pairs of group g's vector work (4 interleaved GELU chains per step).
+// Grid = min(tiles, 256 * k) blocks with tiles <= 2 * grid; virtual tile v of a block b: b, b + grid.
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64, 1) gemm_persist_kernel(const GemmArgs p) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int NW = WM * WN;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(NW == 8 && TM * TN > 20, "the row-split quadrant ping-pong of the large wave tiles");
+  static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU, "consumer epilogues only");
+  constexpr int TMa = (TM + 1) / 2, TMb = TM - TMa, TNa = (TN + 1) / 2, TNb = TN - TNa;
+  constexpr int PA0 = WM * TMa * 2, PA1 = WM * TMb * 2, PB0 = WN * TNa * 2, PB1 = WN * TNb * 2;
+  constexpr int CA0 = (PA0 + 7) / 8, CA1 = (PA1 + 7) / 8, CB0 = (PB0 + 7) / 8, CB1 = (PB1 + 7) / 8;
+  constexpr int CTILE = CA0 + CA1 + CB0 + CB1;
+  // X: bias slice of the tile (BN floats, as whole 1-KiB pieces) + its rows of the row partial sums (BM rows x 16 floats)
+  constexpr int XB_PIECES = (BN * 4 + 1023) / 1024, XP_PIECES = BM * 64 / 1024;
+  constexpr int XB_OFF = 2 * STAGE, XP_OFF = XB_OFF + XB_PIECES * 1024;
+  constexpr int CXP = (XP_PIECES + 7) / 8, CX = 1 + CXP;          // DMA instructions per wave: one bias piece + its partials pieces
+  static_assert(BM * 64 % 1024 == 0, "whole pieces of row partials");
+  // epilogue: 16-row groups, RS-byte slab rows, chunks of 16 B
+  constexpr int RS = TN * 32 + 16, SLAB = 16 * RS, CPR = TN * 2, NCH = (16 * CPR + 63) / 64;
+  constexpr int NST = TM * NCH;                                   // stores per wave per tile
+  static_assert(NW * 2 * SLAB <= STAGE, "slabs live in stage 1");
+  static_assert(NST + CTILE <= 63 && 2 * CTILE + CX <= 63, "vmcnt immediates");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN, grp = wave >> 2;
+  const int tiles_m = p.M / BM, tiles_n = p.N / BN, ntiles = tiles_m * tiles_n;
+  const int nk = p.K / 64;
+  auto coords = [&](int v, int& m0, int& n0) {   // XCD-contiguous chunks of the VIRTUAL tile range, then grouped-M order (as above)
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int first_m = (id / per_group) * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int in_g = id % per_group;
+    m0 = (first_m + in_g % gsz) * BM;
+    n0 = (in_g / gsz) * BN;
+  };
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int a_row_off = (wm * TM * 16 + frow) * 128;
+  const int b_row_off = (wn * TN * 16 + frow) * 128;
+  const int coff0 = ((0 + fg) ^ (frow & 7)) * 16, coff1 = ((4 + fg) ^ (frow & 7)) * 16;
+  // per-lane source offsets (whole tiles: no row clamp, the same for every tile) and wave-uniform LDS offsets of my DMA pieces
+  unsigned oa0[CA0], oa1[CA1], ob0[CB0], ob1[CB1];
+  int la0[CA0], la1[CA1], lb0[CB0], lb1[CB1];
+  auto piece_row = [&](int q, int per, int tiles, int first) {
+    const int w = q / per, in = q - w * per;
+    return w * tiles * 16 + first * 16 + in * 8;
+  };
+#pragma unroll
+  for (int j = 0; j < CA0; ++j) {
+    const int r = piece_row(min(wave + 8 * j, PA0 - 1), TMa * 2, TM, 0);
+    oa0[j] = (unsigned)((r + srow) * (int)p.lda * 2 + schunk * 16);
+    la0[j] = r * 128;
+  }
+#pragma unroll
+  for (int j = 0; j < CA1; ++j) {
+    const int r = piece_row(min(wave + 8 * j, PA1 - 1), TMb * 2, TM, TMa);
+    oa1[j] = (unsigned)((r + srow) * (int)p.lda * 2 + schunk * 16);
+    la1[j] = r * 128;
+  }
+#pragma unroll
+  for (int j = 0; j < CB0; ++j) {
+    const int r = piece_row(min(wave + 8 * j, PB0 - 1), TNa * 2, TN, 0);
+    ob0[j] = (unsigned)((r + srow) * (int)p.ldw * 2 + schunk * 16);
+    lb0[j] = A_BYTES + r * 128;
+  }
+#pragma unroll
+  for (int j = 0; j < CB1; ++j) {
+    const int r = piece_row(min(wave + 8 * j, PB1 - 1), TNb * 2, TN, TNa);
+    ob1[j] = (unsigned)((r + srow) * (int)p.ldw * 2 + schunk * 16);
+    lb1[j] = A_BYTES + r * 128;
+  }
+  const char *a_base, *b_base;      // current tile's first A row / W row (wave-uniform)
+  auto dma_a0 = [&](int st, int kt) {
+#pragma unroll
+    for (int j = 0; j < CA0; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)(a_base + kt * 128 + oa0[j]), (lds_ptr_t)(smem + st * STAGE + la0[j]), 16, 0, 0);
+  };
+  auto dma_a1 = [&](int st, int kt) {
+#pragma unroll
+    for (int j = 0; j < CA1; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)(a_base + kt * 128 + oa1[j]), (lds_ptr_t)(smem + st * STAGE + la1[j]), 16, 0, 0);
+  };
+  auto dma_b0 = [&](int st, int kt) {
+#pragma unroll
+    for (int j = 0; j < CB0; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)(b_base + kt * 128 + ob0[j]), (lds_ptr_t)(smem + st * STAGE + lb0[j]), 16, 0, 0);
+  };
+  auto dma_b1 = [&](int st, int kt) {
+#pragma unroll
+    for (int j = 0; j < CB1; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)(b_base + kt * 128 + ob1[j]), (lds_ptr_t)(smem + st * STAGE + lb1[j]), 16, 0, 0);
+  };
+  auto dma_tile = [&](int st, int kt) { dma_a0(st, kt); dma_b0(st, kt); dma_b1(st, kt); dma_a1(st, kt); };
+  // X of the tile at (m0, n0): every wave issues CX pieces (duplicates rewrite the same bytes).  The bias slice is BN floats:
+  // its last piece is shifted back so that it ends with the slice (pieces overlap instead of reading past it).
+  auto dma_x = [&](int m0, int n0) {
+    {
+      const int q = wave % XB_PIECES;
+      const int foff = min(q * 256, BN - 256);                       // first float of this piece
+      const float* src = (p.bias ? p.bias + n0 : (const float*)p.W) + foff + lane * 4;   // no bias: any readable bytes (unused)
+      __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr_t)(smem + XB_OFF + foff * 4), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < CXP; ++j) {
+      const int q = min(wave + 8 * j, XP_PIECES - 1);
+      const float* src = (p.rs_part ? p.rs_part + (int64_t)m0 * 16 : (const float*)p.A) + q * 256 + lane * 4;
+      __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr_t)(smem + XP_OFF + q * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+  bf16x8 fa[2][TMa], fb[2][TNa];
+  auto rd_a = [&](int st, int i0, int cnt) {
+    const char* sA = smem + st * STAGE + a_row_off + i0 * 2048;
+#pragma unroll
+    for (int i = 0; i < TMa; ++i)
+      if (i < cnt) {
+        fa[0][i] = *(const bf16x8*)(sA + i * 2048 + coff0);
+        fa[1][i] = *(const bf16x8*)(sA + i * 2048 + coff1);
+      }
+  };
+  auto rd_b = [&](int st, int j0, int cnt) {
+    const char* sB = smem + st * STAGE + A_BYTES + b_row_off + j0 * 2048;
+#pragma unroll
+    for (int j = 0; j < TNa; ++j)
+      if (j < cnt) {
+        fb[0][j] = *(const bf16x8*)(sB + j * 2048 + coff0);
+        fb[1][j] = *(const bf16x8*)(sB + j * 2048 + coff1);
+      }
+  };
+#define JAT_Q(I0, IC, J0, JC)                                                                                   \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+  _Pragma("unroll") for (int i = 0; i < (IC); ++i)                                                              \
+  _Pragma("unroll") for (int j = 0; j < (JC); ++j)                                                              \
+    acc[(I0) + i][(J0) + j] = JAT_MFMA_16x16x32(fb[ks][j], fa[ks][i], acc[(I0) + i][(J0) + j], 0, 0, 0);
+#define JAT_LOAD_END()                              \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0);                \
+  __builtin_amdgcn_s_barrier();                     \
+  __builtin_amdgcn_s_setprio(1);
+#define JAT_MMA_END()                 \
+  __builtin_amdgcn_s_setprio(0);      \
+  __builtin_amdgcn_sched_barrier(0);  \
+  __builtin_amdgcn_s_barrier();
+  // the K loop of PIPE 8 (row-split form): on entry K-tile 0 has landed in stage 0 and K-tile 1 is in flight into stage 1
+  auto kloop = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    auto ktile = [&](int t, int st) __attribute__((always_inline)) {
+      const bool more2 = t + 2 < nk;
+      const bool more1 = t >= 1 && t + 1 < nk;
+      rd_b(st, 0, TNa);                       // P1 (A0, B0)
+      __builtin_amdgcn_sched_barrier(0);
+      rd_a(st, 0, TMa);
+      if (more1) dma_b0(st ^ 1, t + 1);
+      JAT_LOAD_END()
+      JAT_Q(0, TMa, 0, TNa)
+      JAT_MMA_END()
+      rd_b(st, TNa, TNb);                     // P2 (A0, B1)
+      if (more2) dma_a0(st, t + 2);
+      JAT_LOAD_END()
+      JAT_Q(0, TMa, TNa, TNb)
+      JAT_MMA_END()
+      rd_a(st, TMa, TMb);                     // P3 (A1, B1)
+      if (more2) dma_b1(st, t + 2);
+      JAT_LOAD_END()
+      JAT_Q(TMa, TMb, TNa, TNb)
+      JAT_MMA_END()
+      rd_b(st, 0, TNa);                       // P4 (A1, B0)
+      if (more2) {
+        dma_a1(st, t + 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA0 + CB1 + CA1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      JAT_LOAD_END()
+      JAT_Q(TMa, TMb, 0, TNa)
+      JAT_MMA_END()
+    };
+    for (int t = 0; t < nk; t += 2) {
+      ktile(t, 0);
+      if (t + 1 < nk) ktile(t + 1, 1);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  };
+#undef JAT_Q
+#undef JAT_LOAD_END
+#undef JAT_MMA_END
+
+  // ---- epilogue of the tile at (m0, n0); `prefetch()` runs right after the barrier that frees the stages and X --------------
+  const float invk = 1.0f / (float)p.K;
+  const unsigned sl0 = (unsigned)(uintptr_t)(lds_ptr_t)(smem + STAGE + wave * (2 * SLAB));   // LDS byte addresses of my two slabs
+  const unsigned sl1 = sl0 + SLAB;
+  const unsigned wslab = frow * RS + fg * 8;                                                 // my 4 packed values of column tile 0
+  int rowt[NCH], soff[NCH], goff[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    const int c = lane + 64 * t;
+    rowt[t] = c / CPR;
+    const int cc = c - rowt[t] * CPR;
+    soff[t] = min(rowt[t], 15) * RS + cc * 16;
+    goff[t] = rowt[t] * (int)p.ldo * 2 + cc * 16;
+  }
+  auto epilogue = [&](int m0, int n0, auto&& prefetch) __attribute__((always_inline)) {
+    float rstd[TM];
+    float4 bb[TN];
+    // 1/rms of my rows from the 16 partial sums per row staged in X, in the order of the one-tile kernels:
+    // chunk sums (x + y) + (z + w), then (c0 + c1) + (c2 + c3)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      rstd[i] = 1.0f;
+      if (p.rs_part) {
+        const char* rp = smem + XP_OFF + (wm * TM * 16 + i * 16 + frow) * 64;
+        const float4 c0 = *(const float4*)rp, c1 = *(const float4*)(rp + 16), c2 = *(const float4*)(rp + 32), c3 = *(const float4*)(rp + 48);
+        const float s0 = (c0.x + c0.y) + (c0.z + c0.w), s1 = (c1.x + c1.y) + (c1.z + c1.w);
+        const float s2 = (c2.x + c2.y) + (c2.z + c2.w), s3 = (c3.x + c3.y) + (c3.z + c3.w);
+        rstd[i] = rsqrtf(((s0 + s1) + (s2 + s3)) * invk + 1e-6f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      bb[j] = p.bias ? *(const float4*)(smem + XB_OFF + (wn * TN * 16 + j * 16 + fg * 4) * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();            // every wave is done with the stages and with X
+    prefetch();
+    char* const obase = (char*)p.out + ((int64_t)(m0 + wm * TM * 16) * p.ldo + n0 + wn * TN * 16) * 2;
+    u32x4 raw[NCH];
+    auto vwrite = [&](auto gc, auto kc) __attribute__((always_inline)) {   // column tiles 2k, 2k+1 of row tile g -> slab[g & 1]
+      constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
+      constexpr int NJ = (2 * k + 1 < TN) ? 2 : 1;
+      f32x2 h[2 * NJ];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const f32x4 v = acc[g][2 * k + jj] * rstd[g];
+        h[2 * jj] = f32x2{v[0] + bb[2 * k + jj].x, v[1] + bb[2 * k + jj].y};
+        h[2 * jj + 1] = f32x2{v[2] + bb[2 * k + jj].z, v[3] + bb[2 * k + jj].w};
+      }
+      if constexpr (EPI == EPI_BF16_GELU) gelu_erf_n<2 * NJ>(h);
+      // The slab accesses are inline asm: the compiler puts s_waitcnt vmcnt(0) in front of every LDS access it can see while
+      // an LDS-DMA is in flight (it cannot tell the slabs from the DMA's destination), which would hold the whole epilogue
+      // until the prefetched K-tile has landed.  Same-wave LDS accesses execute in order; the reads are waited for below.
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const uint2 pk = pack4(h[2 * jj][0], h[2 * jj][1], h[2 * jj + 1][0], h[2 * jj + 1][1]);
+        const unsigned long long pk64 = (unsigned long long)pk.x | ((unsigned long long)pk.y << 32);
+        const unsigned waddr = (g & 1 ? sl1 : sl0) + wslab + ((2 * k + jj) * 32);   // (asm operands must be locals of this lambda)
+        asm volatile("ds_write_b64 %0, %1" ::"v"(waddr), "v"(pk64) : "memory");
+      }
+    };
+    auto sread = [&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      static_for<0, NCH>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        const unsigned raddr = (g & 1 ? sl1 : sl0) + soff[t];
+        u32x4 r;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(raddr) : "memory");
+        raw[t] = r;
+      });
+    };
+    auto swait = [&]() __attribute__((always_inline)) {   // the reads above have returned; no use of raw[] is scheduled above this
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      static_for<0, NCH>([&](auto tc) __attribute__((always_inline)) {
+        u32x4 r = raw[decltype(tc)::value];
+        asm volatile("" : "+v"(r));
+        raw[decltype(tc)::value] = r;
+      });
+    };
+    auto gstore = [&](auto gc, auto tc) __attribute__((always_inline)) {   // issued by EVERY wave for every (g, t): NST is exact
+      constexpr int g = decltype(gc)::value, t = decltype(tc)::value;
+      if (rowt[t] < 16) *(u32x4*)(obase + (int64_t)g * 16 * p.ldo * 2 + goff[t]) = raw[t];
+    };
+    constexpr int NK2 = (TN + 1) / 2;                                    // vector-work steps per group
+    static_assert(NK2 >= NCH, "one store slot per vector-work step");
+    static_for<0, NK2>([&](auto kc) __attribute__((always_inline)) { vwrite(std::integral_constant<int, 0>{}, kc); });
+    static_for<1, TM>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      sread(std::integral_constant<int, g - 1>{});   // same-wave LDS accesses execute in order
+      static_for<0, NK2>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        vwrite(gc, kc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k == 0) swait();
+        if constexpr (k < NCH) gstore(std::integral_constant<int, g - 1>{}, kc);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    sread(std::integral_constant<int, TM - 1>{});
+    swait();
+    static_for<0, NCH>([&](auto tc) __attribute__((always_inline)) { gstore(std::integral_constant<int, TM - 1>{}, tc); });
+  };
+
+  // ---- tile 0 ---------------------------------------------------------------------------------------------------------------
+  const int v0 = blockIdx.x, v1 = blockIdx.x + gridDim.x;
+  const bool two = v1 < ntiles;
+  int m0, n0, m1 = 0, n1 = 0;
+  coords(v0, m0, n0);
+  if (two) coords(v1, m1, n1);
+  a_base = (const char*)(p.A + (int64_t)m0 * p.lda);
+  b_base = (const char*)(p.W + (int64_t)n0 * p.ldw);
+  dma_x(m0, n0);
+  dma_tile(0, 0);
+  if (nk > 1) {
+    dma_tile(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CTILE) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  kloop();
+  epilogue(m0, n0, [&]() __attribute__((always_inline)) {
+    if (two) {   // the second tile's X and first K-tile stream in under this epilogue (stage 0 and X are free; the slabs are in stage 1)
+      a_base = (const char*)(p.A + (int64_t)m1 * p.lda);
+      b_base = (const char*)(p.W + (int64_t)n1 * p.ldw);
+      dma_x(m1, n1);
+      dma_tile(0, 0);
+    }
+  });
+  if (!two) return;
+  // ---- tile 1: its first K-tile (+ X) was issued BEFORE this wave's NST epilogue stores, its second K-tile goes out now --------
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();              // every wave has read its slabs (stage 1) for the last time
+  if (nk > 1) {
+    dma_tile(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + CTILE) : "memory");   // all but my stores and K-tile 1: K-tile 0 and X have landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+  }
+  kloop();
+  epilogue(m1, n1, [&]() __attribute__((always_inline)) {});
+}
+
+static bool gemm_persist_eligible(const GemmArgs& a, int epi) {
+  return (epi == EPI_BF16 || epi == EPI_BF16_GELU) && a.M > 0 && a.M % 224 == 0 && a.N % 320 == 0 && a.K % 64 == 0 && a.ksplit <= 1 &&
+         a.dual_rows == 0 && !a.fold_out && (!a.rs_part || a.rs_np == 16) && a.ldo * 2 * 16 < (1ll << 31) && !(a.dbg & 129);
+}
+template <int EPI>
+static hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
+  constexpr int BM = 224, BN = 320, STAGE = (BM + BN) * 128;
+  constexpr int LDS = 2 * STAGE + 2048 + BM * 64;
+  static_assert(LDS <= 160 * 1024, "stages + bias slice + row partials must fit the 160 KiB LDS");
+  static bool attr_set = false;
+  auto kern = gemm_persist_kernel<2, 4, 7, 5, EPI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles = (a.M / BM) * (a.N / BN);
+  int grid = tiles <= 256 ? tiles : (tiles + 1) / 2;            // two tiles per block once the tiles outnumber the CUs
+  if (grid < 256 && tiles > 256) grid = 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
+  return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, int PIPE, int CE, int EPI>
 static hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -1244,9 +1628,11 @@ static const int kVariantTile[][2] = {
     {224, 320}, {256, 160}, {256, 256}, {128, 448},  // 31-34: PIPE 8 (quadrant ping-pong, 2 LDS stages) + coalesced epilogue
     {224, 256},                                      // 35: PIPE 8
     {224, 320},                                      // 36: the tile of 31 with the software-pipelined bf16 / GELU epilogue (CE == 2)
+    {0, 0},                                          // 37: retired (pipelined split-residual epilogue: slower, profiles/r03)
+    {224, 320},                                      // 38: persistent two-tile form of 36 (gemm_persist_kernel); falls back to 36
 };
 static const int kVariantWaveN[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32, 0, 0, 0, 0, 0, 0, 0,
-                                    80, 0, 64, 64, 0, 0, 0, 80, 64, 80, 64, 0, 0, 80, 80, 64, 112, 64, 80};
+                                    80, 0, 64, 64, 0, 0, 0, 80, 64, 80, 64, 0, 0, 80, 80, 64, 112, 64, 80, 0, 80};
 int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
 bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
@@ -1281,6 +1667,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 33: return launch_epi<2, 4, 8, 4, 8, 1>(a, epi, s);
     case 34: return launch_epi<2, 4, 4, 7, 8, 1>(a, epi, s);
     case 35: return launch_epi<2, 4, 7, 4, 8, 1>(a, epi, s);
+    case 38:
+      if (gemm_persist_eligible(a, epi)) return epi == EPI_BF16 ? launch_persist<EPI_BF16>(a, s) : launch_persist<EPI_BF16_GELU>(a, s);
+      [[fallthrough]];
     case 36: return launch_epi<2, 4, 7, 5, 8, 2>(a, epi, s);
   }
   return hipErrorInvalidValue;

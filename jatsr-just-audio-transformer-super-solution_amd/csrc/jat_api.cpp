@@ -349,6 +349,9 @@ static int pick_variant(int M, int N, int nbatch = 1) {
   // 36: the tile of 31 with the software-pipelined bf16 / GELU epilogue (JAT_EPI_PIPE=0 keeps the plain one: A/B)
   static const int epi_pipe = getenv("JAT_EPI_PIPE") ? atoi(getenv("JAT_EPI_PIPE")) : 1;
   if (epi_pipe && best == 31) best = 36;
+  // 38: the persistent two-tile form of 36 (launch_gemm falls back to 36 for shapes / epilogues it does not take); JAT_PERSIST=0: A/B
+  static const int persist = getenv("JAT_PERSIST") ? atoi(getenv("JAT_PERSIST")) : 1;
+  if (persist && best == 36 && M % 224 == 0 && (long)(M / 224) * (N / 320) * nbatch > 256) best = 38;
   return best;
 }
 

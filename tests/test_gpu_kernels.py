@@ -95,7 +95,7 @@ GEMM_SHAPES = [(128, 128, 64), (256, 512, 128), (1000, 1792, 1280), (56, 1536, 2
 
 # every live tile / pipeline variant of gemm.hip (ids are stable; the structures measured and retired in rounds 1-2 are
 # rejected by launch_gemm: test_retired_gemm_variants_are_rejected); JAT_TEST_VARIANTS="31,32" narrows the sweep
-LIVE_VARIANTS = [10, 18, 20, 21, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36]
+LIVE_VARIANTS = [10, 18, 20, 21, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36, 38]
 GEMM_VARIANTS = [int(v) for v in os.environ.get("JAT_TEST_VARIANTS", "").split(",") if v] or LIVE_VARIANTS
 
 
@@ -206,6 +206,37 @@ def test_gemm_fold_consumer(variant, np_, epi):
                                         None, L.ptr(part), np_, 31, L.stream_ptr()))
         torch.cuda.synchronize()
         assert torch.equal(out, out31)
+
+
+@pytest.mark.parametrize("M,N,K", [(448, 640, 128), (3808, 5120, 64), (3808, 5120, 128), (3808, 5120, 192), (7168, 5120, 1280),
+                                   (57568, 320, 256)])
+@pytest.mark.parametrize("epi,use_part,use_bias", [(2, True, True), (1, True, False), (2, False, True), (1, False, False)])
+def test_gemm_persistent_two_tile_kernel(M, N, K, epi, use_part, use_bias):
+    """Variant 38 (gemm_persist_kernel: one block per CU walks two 224 x 320 tiles, the second tile's first K-tile, bias slice
+    and row statistics prefetched under the first tile's epilogue) is bit-identical to the one-tile kernel (variant 36) and
+    right against fp64: one tile per block, 16 / all blocks with two tiles, 1 / 2 / 3 / 20 K-tiles (every prologue / tail path),
+    with and without the consumer's row statistics and bias."""
+    A, Af = bf16_bits(gen((M, K), 230))
+    W, Wf = bf16_bits(gen((N, K), 231, 1.0 / np.sqrt(K)))
+    bias = gen((N,), 232, 0.1) if use_bias else None
+    part = (gen((M, 16), 233).abs() * K / 16 + 0.1) if use_part else None
+    outs = []
+    for variant in (36, 38):
+        out = torch.full((M, N), float("nan"), device=A.device).to(OP)
+        L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(out), M, N, K, epi, None, 0, 128, None, None, None,
+                                        L.ptr(part), 16 if use_part else 0, variant, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    if M * N <= 3808 * 5120:
+        ref = Af.double() @ Wf.double().T
+        if use_part:
+            ref = ref * torch.rsqrt(part.double().sum(1, keepdim=True) / K + 1e-6)
+        if use_bias:
+            ref = ref + bias.double()
+        if epi == 2:
+            ref = torch.nn.functional.gelu(ref)
+        assert rel(outs[1], ref) < 3e-3
 
 
 @pytest.mark.parametrize("tokens,out,inn,ksplit", [

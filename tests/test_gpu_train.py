@@ -51,6 +51,8 @@ def make_trainer(meta, **kw):
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(".rope." in k for k in missing)
     m = m.to("cuda")
+    if meta.get("loss") == "charbonnier":      # the V3M2-MOD1 trainer's reconstruction loss (train_ddp_v3m2mod1.py:666-672)
+        kw = dict(kw, loss="charbonnier", charbonnier_eps=meta["charbonnier_eps"])
     tr = Trainer(m, batch_size=meta["B"], frames=meta["T"], lr=meta["lr"], weight_decay=meta["wd"],
                  grad_clip=meta["clip"], **kw)
     if FP16 and not kw.get("use_grad_scaler", True):
@@ -70,7 +72,8 @@ def step_inputs(meta):
     return cuda(hr), cuda(lr), cuda(noise), cuda(np.asarray(meta["t"], np.float32)), torch.tensor(meta["mask"])
 
 
-CASES = ["train_micro_T24", "train_micro_T22_pad", "train_micro_ln_T24", "train_tiny_T128", "train_tiny_T1378"]
+CASES = ["train_micro_T24", "train_micro_T22_pad", "train_micro_ln_T24", "train_tiny_T128", "train_tiny_T1378",
+         "train_micro_charbonnier_T24", "train_tiny_charbonnier_T128"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -87,6 +90,57 @@ def test_v3mod2_depth28_step_vs_reference_golden(name):
     fp64 autograd (oracle/gen_golden_train.py `big_case`): loss, clip norm and all 345 parameter gradients (sub-sampled
     values + full L2 norms), at N = 32 tokens and at a ragged T = 70 (padded to 72, N = 18)."""
     _check_step_vs_golden(name, with_adamw=False)
+
+
+@pytest.mark.parametrize("name", ["train_charbonnier_T24", "train_charbonnier_T1378"])
+def test_charbonnier_kernel_vs_reference_function(name):
+    """jat_k_recon_loss (eps > 0) against the reference's charbonnier_loss under autograd (train_ddp_v3m2mod1.py:72-101): value
+    and d/d pred in fp32, elements at |d| ~ sqrt(eps) and d == 0 included; loss_scale scales the gradient only; eps == 0 is
+    F.mse_loss."""
+    z, meta = load_golden(name)
+    B, C, Tn, salt = meta["B"], meta["C"], meta["T"], meta["salt"]
+    pred = recipe.gaussian("charb_pred", (B, C, Tn), salt + 500)
+    target = recipe.gaussian("charb_target", (B, C, Tn), salt + 501)
+    near = recipe.gaussian("charb_near", (B, C, Tn), salt + 502)
+    ft, fp, fn = target.reshape(-1), pred.reshape(-1), near.reshape(-1)
+    ft[::3] = fp[::3] + 2e-3 * fn[::3]
+    ft[::9] = fp[::9]
+    p_d, t_d = cuda(pred), cuda(target)
+    dpred = torch.full_like(p_d, float("nan"))
+    out = torch.zeros(1, device="cuda")
+    work = torch.empty(4104, dtype=torch.uint8, device="cuda")
+    for scale in (1.0, 1024.0):
+        L.check(L.lib().jat_k_recon_loss(L.ptr(p_d), L.ptr(t_d), L.ptr(dpred), L.ptr(out), p_d.numel(), meta["eps"], scale,
+                                         L.ptr(work), work.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert abs(float(out) - float(z["loss64"])) <= 2e-6 * float(z["loss64"])
+        g = dpred.cpu().numpy().astype(np.float64) / scale
+        assert rel_l2(g, z["dpred64"]) < 2e-6
+        assert np.all(g.reshape(-1)[::9] == 0.0)
+    L.check(L.lib().jat_k_recon_loss(L.ptr(p_d), L.ptr(t_d), L.ptr(dpred), L.ptr(out), p_d.numel(), 0.0, 1.0, L.ptr(work),
+                                     work.numel(), L.stream_ptr()))
+    d = pred.astype(np.float64) - target.astype(np.float64)
+    assert abs(float(out) - float((d * d).mean())) <= 2e-6 * float((d * d).mean())
+    assert rel_l2(dpred.cpu().numpy(), 2 * d / d.size) < 2e-6
+
+
+def test_charbonnier_trainer_rejects_the_latent_loss_and_validates():
+    z, meta = load_golden("train_micro_charbonnier_T24")
+    with pytest.raises(ValueError):
+        make_trainer(meta, latent_loss_weight=0.3)
+    m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    hr, lr, noise, t, mask = step_inputs(meta)
+    zero, one = torch.zeros(hr.shape[1], device="cuda"), torch.ones(hr.shape[1], device="cuda")
+    avg, std, metrics = tr.validate([(hr, lr)], zero, one, zero, one, t=[t], noise=[noise])
+    # eval-mode Charbonnier loss of the same batch without the CFG mask: finite, and what the oracle computes
+    from oracle import jat_oracle_train as OT
+    cfg = recipe.CONFIGS[meta["cfg"]]
+    orc = OT.TrainOracle(cfg, recipe.make_state_dict(cfg, meta["norm"], meta["salt"]), meta["norm"])
+    tv = t.view(-1, 1, 1).double().cpu().numpy()
+    z_t = tv * hr.double().cpu().numpy() + (1 - tv) * noise.double().cpu().numpy()
+    ref, _, _ = orc.loss_and_grads(z_t, t.double().cpu().numpy(), lr.double().cpu().numpy(), hr.double().cpu().numpy(),
+                                   charbonnier_eps=meta["charbonnier_eps"])
+    assert metrics == {} and abs(avg - ref) <= 3e-3 * ref
 
 
 def test_v3mod2_B28_step_is_deterministic_and_finite():

@@ -36,12 +36,32 @@ def oracle_step(meta):
     tv = t.reshape(B, 1, 1)
     z_t = tv * hr + (1 - tv) * noise                     # train_ddp_v3m2.py:577-579
     orc = OT.TrainOracle(cfg, sd, meta["norm"])
-    loss, grads, pred = orc.loss_and_grads(z_t, t, lr * keep, hr)
+    charb = meta.get("charbonnier_eps") if meta.get("loss") == "charbonnier" else None
+    loss, grads, pred = orc.loss_and_grads(z_t, t, lr * keep, hr, charbonnier_eps=charb)
     return orc, loss, grads, pred
 
 
+@pytest.mark.parametrize("name", ["train_charbonnier_T24", "train_charbonnier_T1378"])
+def test_charbonnier_oracle_matches_reference_function(name):
+    """oracle charbonnier_loss == the reference's own function (train_ddp_v3m2mod1.py:72-101, AST-extracted, autograd):
+    value and d/d pred, including elements with |pred - target| ~ sqrt(eps) and exactly 0."""
+    z, meta = load_golden(name)
+    B, C, Tn, salt = meta["B"], meta["C"], meta["T"], meta["salt"]
+    pred = recipe.gaussian("charb_pred", (B, C, Tn), salt + 500)
+    target = recipe.gaussian("charb_target", (B, C, Tn), salt + 501)
+    near = recipe.gaussian("charb_near", (B, C, Tn), salt + 502)
+    ft, fp, fn = target.reshape(-1), pred.reshape(-1), near.reshape(-1)
+    ft[::3] = fp[::3] + 2e-3 * fn[::3]
+    ft[::9] = fp[::9]
+    loss, dpred = OT.charbonnier_loss(pred, target, meta["eps"])
+    assert abs(loss - float(z["loss64"])) <= 1e-12
+    assert np.abs(dpred - z["dpred64"]).max() <= 1e-15
+    assert np.all(dpred.reshape(-1)[::9] == 0.0)                       # d == 0: zero gradient, loss sqrt(eps) per element
+    assert abs(float(z["loss32"]) - loss) <= 1e-6                       # the reference's own fp32 run
+
+
 @pytest.mark.parametrize("name", ["train_micro_T24", "train_micro_T22_pad", "train_micro_ln_T24", "train_tiny_T128",
-                                  "train_tiny_T1378"])
+                                  "train_tiny_T1378", "train_micro_charbonnier_T24", "train_tiny_charbonnier_T128"])
 def test_train_oracle_matches_reference_autograd(name):
     z, meta = load_golden(name)
     orc, loss, grads, pred = oracle_step(meta)

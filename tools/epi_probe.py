@@ -48,7 +48,7 @@ def fc1(M, N=5120, K=1280):
         return lambda: L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(out), M, N, K, epi, None, 0, 128,
                                                        None, None, None, L.ptr(part), 16, v, L.stream_ptr()))
     cases = [("v31 K loop only", run(31, 2), 1)]
-    for v in (31, 36):
+    for v in (31, 36, 38):
         cases += [(f"v{v} bf16 store, no GELU", run(v, 1), 0), (f"v{v} GELU, no global stores", run(v, 2), 128),
                   (f"v{v} GELU + stores (the sampler's fc1)", run(v, 2), 0)]
     bench(cases, f"fc1 consumer M={M} N={N} K={K} (rstd from 16 partials, bias)")
