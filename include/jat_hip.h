@@ -206,6 +206,12 @@ int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* C,
 int jat_k_gemm_fold(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K,
                     int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch, uint16_t* hi,
                     uint16_t* lo, float* part_out, const float* part_in, int32_t part_in_np, int32_t variant, void* stream);
+/* Fused QKV projection + RoPE + GQA attention for 128-token samples (the sampler's form of jat_audiosr_v3.py:154-181 when
+ * B * Hkv blocks fill the chip): A [M, K] (M % 128 == 0), Wg = the group-major fused weight [Hkv][5*64 + 64 + 64][K] with q / k rows
+ * pair-interleaved per head (as jat_model_load_weights packs it), out [M, Hkv*320] = attention output; bias / part_in as in
+ * jat_k_gemm_fold's consumer side (folded norms). */
+int jat_k_qkv_attn(const uint16_t* A, const uint16_t* Wg, const float* bias, uint16_t* out, int32_t M, int32_t Hkv, int32_t K,
+                   const float* rope_inv_freq, const float* part_in, int32_t part_in_np, void* stream);
 /* columns per wave tile of a GEMM tile variant (the slot width of part_out); 0 for an unknown variant */
 int jat_k_gemm_wave_n(int32_t variant);
 /* Weight gradient of y = x W^T + b from token-major operands: dW[out,in] = dY[tokens,out]^T X[tokens,in] (fp32), db[out] =

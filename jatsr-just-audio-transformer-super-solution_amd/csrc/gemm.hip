@@ -164,11 +164,17 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
   // whole-kernel timeline (-DJAT_TIMELINE diagnostic build only, tools/tl_probe.py): s_memtime at entry / K loop start / K loop
   // end / after the epilogue's first barrier / exit, s_memrealtime at entry and exit; 8 words per wave, written at exit
 #ifdef JAT_TIMELINE
-  unsigned long long tl_[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl_[7] = {0, 0, 0, 0, 0, 0, 0}, tlx_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tlx_: extra stamps inside an epilogue
 #define JAT_TL(i)                                                                          \
   if (p.dbg_out) {                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_[i])::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  }
+#define JAT_TLX(i)                                                                         \
+  if (p.dbg_out) {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlx_[i])::"memory");      \
     __builtin_amdgcn_sched_barrier(0);                                                     \
   }
 #define JAT_TLR(i)                                                                         \
@@ -181,14 +187,16 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
   {                                                                                        \
     JAT_TL(4) JAT_TLR(6)                                                                   \
     if (p.dbg_out && (threadIdx.x & 63) == 0) {                                            \
-      unsigned long long* o_ = p.dbg_out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8; \
+      unsigned long long* o_ = p.dbg_out + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16; \
       for (int i_ = 0; i_ < 7; ++i_) o_[i_] = tl_[i_];                                     \
       o_[7] = blockIdx.x;                                                                  \
+      for (int i_ = 0; i_ < 8; ++i_) o_[8 + i_] = tlx_[i_];                                \
     }                                                                                      \
   }
   JAT_TL(0) JAT_TLR(5)
 #else
 #define JAT_TL(i)
+#define JAT_TLX(i)
 #define JAT_TLR(i)
 #define JAT_TL_FLUSH()
 #endif
@@ -268,6 +276,16 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
   const int a_row_off = (wm * TM * 16 + frow) * 128;
   const int b_row_off = (wn * TN * 16 + frow) * 128;
   const int coff0 = ((0 + fg) ^ (frow & 7)) * 16, coff1 = ((4 + fg) ^ (frow & 7)) * 16;
+  // Which 16-row tile of the W image wave column w reads as its column tile j.  Plain GEMMs: wave-column-major.  Fused QKV +
+  // attention (W rows group-major: 20 q tiles, 4 k tiles, 4 v tiles): every wave column gets five q tiles, ONE k tile (j = 5) and
+  // ONE v tile (j = 6), so that the RoPE / operand-image phase is balanced over the waves and "which kind of tile" is a
+  // compile-time property of j (the v tile is computed with swapped MFMA operands: see the epilogue).
+  constexpr bool QA = EPI == EPI_QKV_ATTN;
+  static_assert(!QA || (TN == 7 && WN == 4), "fused QKV + attention: 5 q + k + v tiles per wave column");
+  auto ctile = [](int w, int j) { return QA ? (j < 5 ? w * 5 + j : j == 5 ? 20 + w : 24 + w) : w * TN + j; };
+  auto b_frag_off = [&](int j) {   // byte offset of my fragment row of column tile j inside the W image (j: compile-time after unrolling)
+    return QA ? ctile(wn, j) * 2048 + frow * 128 : b_row_off + j * 2048;
+  };
 
   auto read_frags = [&](bf16x8(&af)[TM], bf16x8(&wf)[TN], int st, int coff) {
     const char* sA = smem + st * STAGE;
@@ -441,15 +459,19 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
       oa1[j] = (unsigned)((min(m0 + r + srow, p.M - 1) - m0) * (int)p.lda * 2 + schunk * 16);
       la1[j] = r * 128;
     }
+    auto piece_row_b = [&](int q, int per, int first) {   // the same for a B part, through the column-tile map
+      const int w = q / per, in = q - w * per;
+      return ctile(w, first + (in >> 1)) * 16 + (in & 1) * 8;
+    };
 #pragma unroll
     for (int j = 0; j < CB0; ++j) {
-      const int r = piece_row(min(wave + 8 * j, PB0 - 1), TNa * 2, TN, 0);
+      const int r = piece_row_b(min(wave + 8 * j, PB0 - 1), TNa * 2, 0);
       ob0[j] = (unsigned)((r + srow) * (int)p.ldw * 2 + schunk * 16);
       lb0[j] = A_BYTES + r * 128;
     }
 #pragma unroll
     for (int j = 0; j < CB1; ++j) {
-      const int r = piece_row(min(wave + 8 * j, PB1 - 1), TNb * 2, TN, TNa);
+      const int r = piece_row_b(min(wave + 8 * j, PB1 - 1), TNb * 2, TNa);
       ob1[j] = (unsigned)((r + srow) * (int)p.ldw * 2 + schunk * 16);
       lb1[j] = A_BYTES + r * 128;
     }
@@ -484,19 +506,33 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
         }
     };
     auto rd_b = [&](int st, int j0, int cnt) {
-      const char* sB = smem + st * STAGE + A_BYTES + b_row_off + j0 * 2048;
+      if constexpr (QA) {
+        const char* sB = smem + st * STAGE + A_BYTES;
 #pragma unroll
-      for (int j = 0; j < TNa; ++j)
-        if (j < cnt) {
-          fb[0][j] = *(const bf16x8*)(sB + j * 2048 + coff0);
-          fb[1][j] = *(const bf16x8*)(sB + j * 2048 + coff1);
-        }
+        for (int j = 0; j < TNa; ++j)
+          if (j < cnt) {
+            fb[0][j] = *(const bf16x8*)(sB + b_frag_off(j0 + j) + coff0);
+            fb[1][j] = *(const bf16x8*)(sB + b_frag_off(j0 + j) + coff1);
+          }
+      } else {
+        const char* sB = smem + st * STAGE + A_BYTES + b_row_off + j0 * 2048;
+#pragma unroll
+        for (int j = 0; j < TNa; ++j)
+          if (j < cnt) {
+            fb[0][j] = *(const bf16x8*)(sB + j * 2048 + coff0);
+            fb[1][j] = *(const bf16x8*)(sB + j * 2048 + coff1);
+          }
+      }
     };
+    // fused QKV + attention: the v tile (j = TN - 1) with the operands swapped, D[token][feature]: a lane then holds 4 consecutive
+    // KEYS of one feature, which is 8 contiguous bytes of the V^T operand image
 #define JAT_Q(I0, IC, J0, JC)                                                                                   \
   if (!abl_mma) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
   _Pragma("unroll") for (int i = 0; i < (IC); ++i)                                                              \
   _Pragma("unroll") for (int j = 0; j < (JC); ++j)                                                              \
-    acc[(I0) + i][(J0) + j] = JAT_MFMA_16x16x32(fb[ks][j], fa[ks][i], acc[(I0) + i][(J0) + j], 0, 0, 0);
+    acc[(I0) + i][(J0) + j] = (QA && (J0) + j == TN - 1)                                                        \
+        ? JAT_MFMA_16x16x32(fa[ks][i], fb[ks][j], acc[(I0) + i][(J0) + j], 0, 0, 0)                             \
+        : JAT_MFMA_16x16x32(fb[ks][j], fa[ks][i], acc[(I0) + i][(J0) + j], 0, 0, 0);
 #define JAT_LOAD_END()                              \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0);                \
@@ -1003,47 +1039,62 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
     constexpr int SQ = 0, SK = 5 * 16384, SV = SK + 16384;
     static_assert(SV + 16384 <= 2 * STAGE, "operand images do not fit the staging buffers");
     __builtin_amdgcn_s_barrier();
-    if (p.dbg & 64) return;    // timing aid: K loop only
-    float2 invf[TN];
+    JAT_TL(3)
+    if (p.dbg & 64) { JAT_TL_FLUSH() return; }    // timing aid: K loop only
+    // Column tiles of this wave (ctile): j < 5 the q tiles 5 wn + j, j = 5 its k tile, j = 6 its v tile (swapped operands).
+    // RoPE angles: tile c covers the pair-interleaved features (16 c) % 64 ... of a head, i.e. frequencies 8 (c % 4) + 2 fg, +1;
+    // c % 4 = (wn + j) % 4 for the q tiles and wn % 4 for the k tile: FOUR angle sets per row tile serve its six RoPE tiles
+    // (set s: frequencies of (wn + s) % 4; tile j uses set j % 4, the k tile set 0).  v_sin / v_cos of fract(pos * inv_freq / 2 pi),
+    // evaluated in registers (a table lookup is a 16-cache-line gather per instruction).
+    float2 invf[4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int d0 = (((wn * TN * 16 + j * 16) & 63) >> 1) + fg * 2;
-      invf[j] = *(const float2*)(p.rope_inv_freq + d0);
-    }
+    for (int sidx = 0; sidx < 4; ++sidx) invf[sidx] = *(const float2*)(p.rope_inv_freq + ((wn + sidx) & 3) * 8 + fg * 2);
+    float4 bqk[6];
+    float bvs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      bqk[j] = p.bias ? *(const float4*)(p.bias + n0 + ctile(wn, j) * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bvs = p.bias[n0 + ctile(wn, 6) * 16 + frow];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int r = wm * TM * 16 + i * 16 + frow;  // token position inside the sample (m0 = b * 128)
+      float cs[4][4];                              // [set]: cos0, cos1, sin0, sin1
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nl = wn * TN * 16 + j * 16;      // tile-local first column of this MFMA tile (wave-uniform)
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const float r0 = __builtin_amdgcn_fractf((float)r * invf[sidx].x * 0.15915494309189535f);
+        const float r1 = __builtin_amdgcn_fractf((float)r * invf[sidx].y * 0.15915494309189535f);
+        cs[sidx][0] = __builtin_amdgcn_cosf(r0); cs[sidx][1] = __builtin_amdgcn_cosf(r1);
+        cs[sidx][2] = __builtin_amdgcn_sinf(r0); cs[sidx][3] = __builtin_amdgcn_sinf(r1);
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int nl = ctile(wn, j) * 16;          // tile-local first column of this MFMA tile (wave-uniform)
         f32x4 v = acc[i][j] * rstd_rows[i];
-        if (p.bias) {   // folded norm: shift @ W^T of this step and layer, in the group-major column order of W
-          const float4 bq = *(const float4*)(p.bias + n0 + nl + fg * 4);
-          v[0] += bq.x; v[1] += bq.y; v[2] += bq.z; v[3] += bq.w;
-        }
-        if (nl < 384) {
-          const float r0 = __builtin_amdgcn_fractf((float)r * invf[j].x * 0.15915494309189535f);
-          const float r1 = __builtin_amdgcn_fractf((float)r * invf[j].y * 0.15915494309189535f);
-          const float c0 = __builtin_amdgcn_cosf(r0), c1 = __builtin_amdgcn_cosf(r1);
-          const float s0 = __builtin_amdgcn_sinf(r0), s1 = __builtin_amdgcn_sinf(r1);
-          const float2 r01 = rope_rot(v[0], v[1], c0, s0), r23 = rope_rot(v[2], v[3], c1, s1);
-          const uint2 pk = pack4(r01.x, r01.y, r23.x, r23.y);
-          const int colb = ((nl & 63) + fg * 4) * 2, chunk = colb >> 4, off = colb & 15;
-          if (nl < 320) *(uint2*)(smem + SQ + (nl >> 6) * 16384 + r * 128 + ((chunk ^ (r & 7)) << 4) + off) = pk;
-          else *(uint2*)(smem + SK + r * 128 + ((chunk ^ ((r & 3) | (((r >> 3) & 1) << 2))) << 4) + off) = pk;
-        } else {
-          const int d0 = (nl - 384) + fg * 4;
+        if (p.bias) { v[0] += bqk[j].x; v[1] += bqk[j].y; v[2] += bqk[j].z; v[3] += bqk[j].w; }   // folded norm: shift @ W^T
+        constexpr int NSET[6] = {0, 1, 2, 3, 0, 0};
+        const float* a4 = cs[NSET[j]];
+        const float2 r01 = rope_rot(v[0], v[1], a4[0], a4[2]), r23 = rope_rot(v[2], v[3], a4[1], a4[3]);
+        const uint2 pk = pack4(r01.x, r01.y, r23.x, r23.y);
+        const int colb = ((nl & 63) + fg * 4) * 2, chunk = colb >> 4, off = colb & 15;
+        if (j < 5) *(uint2*)(smem + SQ + (nl >> 6) * 16384 + r * 128 + ((chunk ^ (r & 7)) << 4) + off) = pk;
+        else *(uint2*)(smem + SK + r * 128 + ((chunk ^ ((r & 3) | (((r >> 3) & 1) << 2))) << 4) + off) = pk;
+      }
+      {  // v tile, D[token][feature]: this lane holds keys rk .. rk + 3 of feature d -> 8 contiguous bytes of V^T [64][128]
+        const int rk = wm * TM * 16 + i * 16 + fg * 4, d = (ctile(wn, 6) - 24) * 16 + frow, kc = rk >> 3;
+        float vv[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int d = d0 + e, kc = r >> 3;
-            *(unsigned short*)(smem + SV + d * 256 + (kc >> 3) * 128 + (((kc & 7) ^ (d & 7)) << 4) + (r & 7) * 2) = f2bf(v[e]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          vv[e] = acc[i][6][e] * __shfl(rstd_rows[i], fg * 4 + e);   // rstd of token rk + e sits in the lane whose frow is 4 fg + e
+          if (p.bias) vv[e] += bvs;
         }
+        *(uint2*)(smem + SV + d * 256 + (kc >> 3) * 128 + (((kc & 7) ^ (d & 7)) << 4) + (rk & 7) * 2) = pack4(vv[0], vv[1], vv[2], vv[3]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    JAT_TLX(0)
     __builtin_amdgcn_s_barrier();
-    if (p.dbg & 32) return;    // timing aid: no attention phase
+    JAT_TLX(1)
+    if (p.dbg & 32) { JAT_TL_FLUSH() return; }    // timing aid: no attention phase
     const int q = wave * 16 + frow;                // this lane's query row (B-operand column)
     constexpr int G = 5;
     const int hbase = (n0 / 448) * G;
@@ -1075,6 +1126,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
         st[h][kt] = JAT_MFMA_16x16x32(kf1, qf[h][1], st[h][kt], 0, 0, 0);
       }
     }
+    JAT_TLX(2)
     float inv[G];
     bf16x8 pf[G][4];
 #pragma unroll
@@ -1102,6 +1154,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
         pf[h][kk] = jat_pack8(st[h][2 * kk], st[h][2 * kk + 1]);
       }
     }
+    JAT_TLX(3)
     f32x4 o[G][4];
 #pragma unroll
     for (int h = 0; h < G; ++h)
@@ -1116,6 +1169,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
 #pragma unroll
         for (int h = 0; h < G; ++h) o[h][dt] = JAT_MFMA_16x16x32(vf, pf[h][kk], o[h][dt], 0, 0, 0);
       }
+    JAT_TLX(4)
     if (m0 + q < p.M) {
 #pragma unroll
       for (int h = 0; h < G; ++h) {
@@ -1125,6 +1179,7 @@ __global__ void __launch_bounds__((WM * WN + (PIPE == 6 ? 4 : 0)) * 64, (WM * WN
           *(uint2*)(op + dt * 16) = pack4(o[h][dt][0] * inv[h], o[h][dt][1] * inv[h], o[h][dt][2] * inv[h], o[h][dt][3] * inv[h]);
       }
     }
+    JAT_TL_FLUSH()
     return;
   }
 

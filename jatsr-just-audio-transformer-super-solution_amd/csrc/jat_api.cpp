@@ -1041,6 +1041,21 @@ extern "C" int jat_k_gemm_fold(const uint16_t* A, const uint16_t* W, const float
   KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
   return JAT_OK;
 }
+// per-kernel entry point (unit parity, tools/tl_probe.py): fused QKV projection + RoPE + GQA attention of 128-token samples,
+// W = group-major fused weight [Hkv][5*64 + 64 + 64][K] (q / k rows pair-interleaved per head), out = attention output [M, Hkv*320]
+extern "C" int jat_k_qkv_attn(const uint16_t* A, const uint16_t* Wg, const float* bias, uint16_t* out, int32_t M, int32_t Hkv,
+                              int32_t K, const float* rope_inv_freq, const float* part_in, int32_t part_in_np, void* stream) {
+  if (!A || !Wg || !out || !rope_inv_freq || M <= 0 || M % 128 != 0 || K % 64 != 0) return fail(JAT_E_INVALID, "bad argument");
+  GemmArgs a{};
+  a.A = A; a.lda = K; a.W = Wg; a.ldw = K; a.M = M; a.N = Hkv * 448; a.K = K;
+  a.out = out; a.ldo = (int64_t)Hkv * 320; a.ntok = 128; a.rope_inv_freq = rope_inv_freq; a.bias = bias;
+  a.attn_scale_log2e = 0.125f * 1.4426950408889634f;
+  a.rs_part = part_in; a.rs_np = part_in_np;
+  if (const char* d = getenv("JAT_GEMM_DBG")) a.dbg = atoi(d);
+  if (const char* d = getenv("JAT_GEMM_TIMELINE")) a.dbg_out = (unsigned long long*)strtoull(d, nullptr, 0);
+  KCHK(launch_qkv_attn(a, (hipStream_t)stream));
+  return JAT_OK;
+}
 extern "C" int jat_k_weight_grad(const uint16_t* dY, const uint16_t* X, float* dW, float* db, int32_t tokens, int32_t out,
                                  int32_t in, int32_t ksplit, void* work, size_t work_bytes, void* stream) {
   if (!gemm_tn_supports(out, in)) return fail(JAT_E_INVALID, "out and in must be multiples of 128");

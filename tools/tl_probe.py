@@ -12,7 +12,7 @@ import torch
 import jatsr_amd._lib as L
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--shape", default="fc1", choices=["fc1", "fc2", "out"])
+ap.add_argument("--shape", default="fc1", choices=["fc1", "fc2", "out", "qkvattn"])
 ap.add_argument("--variant", type=int, default=36)
 ap.add_argument("--M", type=int, default=7168)
 ap.add_argument("--dbg", type=int, default=0)
@@ -20,7 +20,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 OP = torch.bfloat16
 M = a.M
-N, K, epi = {"fc1": (5120, 1280, 2), "fc2": (1280, 5120, 3), "out": (1280, 1280, 3)}[a.shape]
+N, K, epi = {"fc1": (5120, 1280, 2), "fc2": (1280, 5120, 3), "out": (1280, 1280, 3), "qkvattn": (1792, 1280, -1)}[a.shape]
 A = torch.randn(M, K, device=dev).to(OP)
 W = (torch.randn(N, K, device=dev) / K ** 0.5).to(OP)
 bias = torch.randn(N, device=dev) * 0.05
@@ -31,11 +31,17 @@ hi = x0.to(OP)
 lo = (x0 - hi.float()).to(OP)
 part_out = torch.zeros(M, 16, device=dev)
 out = torch.zeros(M, N, dtype=OP, device=dev)
-buf = torch.zeros(4096 * 8 * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device=dev)
+invf = torch.tensor([1.0 / 10000.0 ** (2 * i / 64.0) for i in range(32)], dtype=torch.float32, device=dev)
+qbias = torch.randn(1792, device=dev) * 0.05
+ao = torch.zeros(M, 1280, dtype=OP, device=dev)
 
 
 def run():
-    if epi == 2:
+    if epi == -1:
+        L.check(L.lib().jat_k_qkv_attn(L.ptr(A), L.ptr(W), L.ptr(qbias), L.ptr(ao), M, 4, K, L.ptr(invf), L.ptr(part_in), 16,
+                                       L.stream_ptr()))
+    elif epi == 2:
         L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(out), M, N, K, 2, None, 0, 128, None, None, None,
                                         L.ptr(part_in), 16, a.variant, L.stream_ptr()))
     else:
@@ -51,7 +57,7 @@ os.environ["JAT_GEMM_TIMELINE"] = str(buf.data_ptr())
 for _ in range(5):
     run()
 torch.cuda.synchronize()
-t = buf.view(-1, 8).cpu()
+t = buf.view(-1, 16).cpu()
 t = t[t[:, 0] != 0].double()
 nb = int(t[:, 7].max()) + 1
 seg = {"entry -> K loop start (prologue)": t[:, 1] - t[:, 0], "K loop": t[:, 2] - t[:, 1], "K loop end -> epilogue barrier passed": t[:, 3] - t[:, 2],
@@ -61,6 +67,12 @@ clk = float(((t[:, 4] - t[:, 0]) / real).median())   # cycles per ns = GHz
 print(f"{a.shape} M={M} N={N} K={K} variant {a.variant} dbg={a.dbg}: {len(t)} waves of {nb} blocks, clock {clk:.2f} GHz")
 for k, v in seg.items():
     print(f"  {k:42s} median {float(v.median()):9.0f} cyc = {float(v.median()) / clk / 1e3:6.2f} us   (p10 {float(v.quantile(0.1)) / clk / 1e3:6.2f}, p90 {float(v.quantile(0.9)) / clk / 1e3:6.2f})")
+if epi == -1:
+    x = t[:, 8:13]
+    for k, v in {"RoPE + operand images (barrier -> images written)": x[:, 0] - t[:, 3], "wait at the image barrier": x[:, 1] - x[:, 0],
+                 "Q fragments + 80 QK^T MFMAs": x[:, 2] - x[:, 1], "5 softmaxes (max, exp2, sum, pack)": x[:, 3] - x[:, 2],
+                 "80 PV MFMAs": x[:, 4] - x[:, 3], "normalise + store": t[:, 4] - x[:, 4]}.items():
+        print(f"    {k:52s} median {float(v.median()):9.0f} cyc = {float(v.median()) / clk / 1e3:6.2f} us   (p10 {float(v.quantile(0.1)) / clk / 1e3:6.2f}, p90 {float(v.quantile(0.9)) / clk / 1e3:6.2f})")
 span = (float(t[:, 6].max()) - float(t[:, 5].min())) * 10.0 / 1e3
 print(f"  launch span, first entry -> last exit (s_memrealtime) {span:7.2f} us; entries spread over {(float(t[:, 5].max()) - float(t[:, 5].min())) * 10 / 1e3:6.2f} us")
 # second-round blocks: entries later than the earliest exit
