@@ -1613,6 +1613,257 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) gemm_persist_kernel(const Gem
   epilogue(m1, n1, [&]() __attribute__((always_inline)) {});
 }
 
+// -----------------------------------------------------------------------------------------------------
+// k-step-pair GEMM for the gated-residual PRODUCER GEMMs of the sampler (out_proj, MLP fc2: N = 1280): a 224 x 160 block tile so
+// that M = 7168 gives 32 x 8 = 256 tiles = every CU (the 256 x 160 tile of variants 25 / 32 fills 224 of 256 CUs, and no 8-wave
+// tiling of 224 x 160 exists: 140 MFMA tiles do not divide by 8).  Here the 8 waves are TWO groups of 2 x 2 waves that compute
+// the SAME 224 x 160 tile (wave tile 112 x 80 = 7 x 5 MFMA tiles, as the fc1 kernels) over different halves of K: group g takes
+// k-step g (32 columns) of every 64-column K-tile.  The two waves of a SIMD (w, w + 4) run one barrier apart as in PIPE 8 —
+//     interval 2k   : group 0 reads its fragments of K-tile k      | group 1: 35 MFMAs on K-tile k-1
+//     interval 2k+1 : group 0: 35 MFMAs on K-tile k                | group 1 reads its fragments of K-tile k
+// — a wave holds ONE k-step of fragments (48 VGPRs, no quadrant cut), 2 phases and 4 barriers per K-tile instead of 4 and 8,
+// 12 instead of 18 fragment reads per 35 / 40 MFMAs.  THREE LDS stages (K-tile k in stage k % 3, 48 KiB each): the DMA of K-tile
+// k+3 is issued in the load phase of K-tile k+1 (by then both groups have read K-tile k) and has two K-tiles to land; each
+// wave waits for its own pieces of K-tile k+1 with a counted vmcnt at the end of its load phase of K-tile k, one barrier
+// before anyone reads them.  After the K loop the groups exchange halves of their partial accumulators through LDS (group 0
+// keeps row tiles 0-3 of its wave tile, group 1 row tiles 4-6; fp32 a + b in either order is the same number), and all 8 waves
+// run the split-residual epilogue of the one-tile kernels on their half.
+template <int EPI>
+__global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
+  constexpr int TM = 7, TN = 5, BM = 224, BN = 160, NW = 8;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int PIECES = (BM + BN) / 8, CP = PIECES / NW;            // 48 one-KiB pieces per K-tile, 6 per wave
+  static_assert(PIECES % NW == 0, "every wave issues the same number of DMA pieces");
+  static_assert(EPI == EPI_RESID || EPI == EPI_F32, "split-residual producer epilogues");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3, wm = wq >> 1, wn = wq & 1;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int tiles_m = p.M / BM, tiles_n = p.N / BN;
+  int m0, n0;
+  {  // XCD-contiguous chunks, grouped-M order (as gemm_bf16_kernel)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int first_m = (id / per_group) * GROUP;
+    const int gsz = min(tiles_m - first_m, GROUP);
+    const int in_g = id % per_group;
+    m0 = (first_m + in_g % gsz) * BM;
+    n0 = (in_g / gsz) * BN;
+  }
+  const int nk = p.K / 64;
+  // my DMA pieces: piece q = wave + 8 j covers image rows 8 q .. 8 q + 7 (A rows first, then W rows); whole tiles: no clamp
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const char* psrc[CP];
+  int pdst[CP];
+#pragma unroll
+  for (int j = 0; j < CP; ++j) {
+    const int q = wave + NW * j, r = q * 8;
+    pdst[j] = r * 128;
+    psrc[j] = r < BM ? (const char*)(p.A + (int64_t)(m0 + r + srow) * p.lda) + schunk * 16
+                     : (const char*)(p.W + (int64_t)(n0 + r - BM + srow) * p.ldw) + schunk * 16;
+  }
+  auto dma_tile = [&](int kt) {
+    char* st = smem + (kt % 3) * STAGE;
+#pragma unroll
+    for (int j = 0; j < CP; ++j)
+      __builtin_amdgcn_global_load_lds((const void*)(psrc[j] + kt * 128), (lds_ptr_t)(st + pdst[j]), 16, 0, 0);
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[TM], fb[TN];
+  const int a_off = (wm * TM * 16 + frow) * 128 + ((4 * grp + fg) ^ (frow & 7)) * 16;               // my k-step's chunk, swizzled
+  const int b_off = A_BYTES + (wn * TN * 16 + frow) * 128 + ((4 * grp + fg) ^ (frow & 7)) * 16;
+  auto rd = [&](int kt) {
+    const char* st = smem + (kt % 3) * STAGE;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8*)(st + b_off + j * 2048);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8*)(st + a_off + i * 2048);
+  };
+  // prologue: K-tiles 0, 1, 2 in flight; tile 0 landed
+  dma_tile(0);
+  if (nk > 1) dma_tile(1);
+  if (nk > 2) dma_tile(2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CP) : "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    // load phase of K-tile kt (my pieces of K-tile kt+1 were waited for at the end of the previous load phase)
+    rd(kt);
+    if (kt >= 1 && kt + 2 < nk) dma_tile(kt + 2);          // stage of K-tile kt-1: both groups finished reading it an interval ago
+    if (kt + 1 < nk) {
+      if (kt >= 1 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CP) : "memory");   // all but the pieces just issued
+      else if (kt == 0 && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CP) : "memory");   // prologue: tile 2 may still fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = JAT_MFMA_16x16x32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  // ---- exchange: every wave is past its last fragment read (the barrier above) -------------------------------------------
+  // slot (wq, direction): group 1 -> group 0 row tiles 0..3 (20 accumulator tiles), group 0 -> group 1 row tiles 4..6 (15)
+  constexpr int XA = 20 * 1024, XB = 15 * 1024;
+  char* xa = smem + wq * (XA + XB);
+  char* xb = xa + XA;
+  static_assert(4 * (XA + XB) <= 3 * STAGE, "exchange buffers fit the stages");
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) *(f32x4*)(xa + ((i * TN + j) * 64 + lane) * 16) = acc[i][j];
+  } else {
+#pragma unroll
+    for (int i = 4; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) *(f32x4*)(xb + (((i - 4) * TN + j) * 64 + lane) * 16) = acc[i][j];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += *(const f32x4*)(xa + ((i * TN + j) * 64 + lane) * 16);
+  } else {
+#pragma unroll
+    for (int i = 4; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] += *(const f32x4*)(xb + (((i - 4) * TN + j) * 64 + lane) * 16);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // the exchange buffers are consumed: the slabs below may overwrite them
+  if (p.dbg & 1) return;
+  // ---- split-residual epilogue (see gemm_bf16_kernel) on my half: row tiles [I0, I0 + NT) of the wave tile ---------------------
+  constexpr int RS = TN * 64 + 16, CPR8 = TN * 2, NCH8 = TN;
+  static_assert(NW * 32 * RS <= 3 * STAGE, "epilogue slabs fit the stages");
+  char* wbuf = smem + wave * (32 * RS);
+  const int nw0 = n0 + wn * TN * 16;
+  float4 bb[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+  auto up = [](unsigned u, float& a, float& b) { a = jat_lo2f(u); b = jat_hi2f(u); };
+  auto half_epilogue = [&](auto i0c, auto ntc) __attribute__((always_inline)) {
+    constexpr int I0 = decltype(i0c)::value, NT = decltype(ntc)::value;
+    const int mw0 = m0 + wm * TM * 16 + I0 * 16;
+#pragma unroll
+    for (int ig = 0; ig < (NT + 1) / 2; ++ig) {
+      const int grows = (2 * ig + 1 < NT) ? 32 : 16;
+      [[maybe_unused]] uint4 hi[NCH8], lo[NCH8];
+      [[maybe_unused]] float4 g0[NCH8], g1[NCH8];
+      if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int t = 0; t < NCH8; ++t) {
+          const int c = lane + 64 * t, row = min(c / CPR8, grows - 1), cc = c - (c / CPR8) * CPR8;
+          const int m = mw0 + ig * 32 + row, n = nw0 + cc * 8;
+          const unsigned off = (unsigned)(m * (int)p.ldo + n) * 2u;   // uniform base + 32-bit lane offset (planes < 4 GB)
+          hi[t] = *(const uint4*)((const char*)p.fold_out + off);
+          lo[t] = *(const uint4*)((const char*)p.fold_lo + off);
+          const float* gp = p.gate + (int64_t)(m / p.ntok) * p.gate_bstride + n;
+          g0[t] = *(const float4*)gp;
+          g1[t] = *(const float4*)(gp + 4);
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) if (2 * ig + ii < NT) {
+          const f32x4 v = acc[I0 + (2 * ig + ii < NT ? 2 * ig + ii : 0)][j];
+          *(float4*)(wbuf + (ii * 16 + frow) * RS + (j * 16 + fg * 4) * 4) =
+              float4{v[0] + bb[j].x, v[1] + bb[j].y, v[2] + bb[j].z, v[3] + bb[j].w};
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < NCH8; ++t) {
+        const int c = lane + 64 * t, row = c / CPR8, cc = c - row * CPR8;
+        const int m = mw0 + ig * 32 + row, n = nw0 + cc * 8;
+        char* slot = wbuf + (row < 32 ? row : 0) * RS + cc * 32;
+        const float4 a0 = *(const float4*)slot, a1 = *(const float4*)(slot + 16);
+        float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        if constexpr (EPI == EPI_RESID) {
+          const unsigned hw[4] = {hi[t].x, hi[t].y, hi[t].z, hi[t].w}, lw[4] = {lo[t].x, lo[t].y, lo[t].z, lo[t].w};
+          const float gg[8] = {g0[t].x, g0[t].y, g0[t].z, g0[t].w, g1[t].x, g1[t].y, g1[t].z, g1[t].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float h0, h1, l0, l1;
+            up(hw[e], h0, h1);
+            up(lw[e], l0, l1);
+            x[2 * e] = __builtin_fmaf(gg[2 * e], x[2 * e], h0 + l0);
+            x[2 * e + 1] = __builtin_fmaf(gg[2 * e + 1], x[2 * e + 1], h1 + l1);
+          }
+        }
+        unsigned ho[4], lw2[4];
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned short ha = f2bf(x[2 * e]), hb = f2bf(x[2 * e + 1]);
+          ho[e] = (unsigned)ha | ((unsigned)hb << 16);
+          const float ra = x[2 * e] - jat_op2f(ha), rb = x[2 * e + 1] - jat_op2f(hb);
+          lw2[e] = jat_pack2(ra, rb);
+          sq += x[2 * e] * x[2 * e] + x[2 * e + 1] * x[2 * e + 1];
+        }
+        const bool live = row < grows;
+        if (live && !(p.dbg & 128)) {
+          const unsigned off = (unsigned)(m * (int)p.ldo + n) * 2u;
+          *(uint4*)((char*)p.fold_out + off) = uint4{ho[0], ho[1], ho[2], ho[3]};
+          *(uint4*)((char*)p.fold_lo + off) = uint4{lw2[0], lw2[1], lw2[2], lw2[3]};
+        }
+        if (row < 32) *(float*)slot = live ? sq : 0.f;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {  // row partial sums over this wave's columns: two lanes per row, fixed order
+        constexpr int HALF = CPR8 / 2;
+        const int r = lane >> 1, h = lane & 1;
+        float sq = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < HALF; ++cc) sq += *(const float*)(wbuf + r * RS + (h * HALF + cc) * 32);
+        sq += __shfl_xor(sq, 1);
+        const int m = mw0 + ig * 32 + r;
+        if (h == 0 && r < grows) p.fold_part[(int64_t)m * p.fold_np + nw0 / (TN * 16)] = sq;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  if (grp == 0) half_epilogue(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+  else half_epilogue(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+}
+
+static bool gemm_kpair_eligible(const GemmArgs& a, int epi) {
+  return (epi == EPI_RESID || epi == EPI_F32) && a.fold_out && a.fold_lo && a.fold_part && a.M > 0 && a.M % 224 == 0 &&
+         a.N % 160 == 0 && a.K % 64 == 0 && a.ksplit <= 1 && !a.rs_part;
+}
+template <int EPI>
+static hipError_t launch_kpair(const GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = 3 * (224 + 160) * 128;
+  static_assert(LDS <= 160 * 1024, "three stages must fit the 160 KiB LDS");
+  static bool attr_set = false;
+  auto kern = gemm_kpair_kernel<EPI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.M / 224) * (a.N / 160)), dim3(512), LDS, s, a);
+  return hipGetLastError();
+}
+
 static bool gemm_persist_eligible(const GemmArgs& a, int epi) {
   return (epi == EPI_BF16 || epi == EPI_BF16_GELU) && a.M > 0 && a.M % 224 == 0 && a.N % 320 == 0 && a.K % 64 == 0 && a.ksplit <= 1 &&
          a.dual_rows == 0 && !a.fold_out && (!a.rs_part || a.rs_np == 16) && a.ldo * 2 * 16 < (1ll << 31) && !(a.dbg & 129);
@@ -1685,9 +1936,11 @@ static const int kVariantTile[][2] = {
     {224, 320},                                      // 36: the tile of 31 with the software-pipelined bf16 / GELU epilogue (CE == 2)
     {0, 0},                                          // 37: retired (pipelined split-residual epilogue: slower, profiles/r03)
     {224, 320},                                      // 38: persistent two-tile form of 36 (gemm_persist_kernel); falls back to 36
+    {256, 160},                                      // 39: k-step-pair 224 x 160 tile for the split-residual producers (gemm_kpair_kernel);
+                                                     //     falls back to 32 (whose tile this entry reports)
 };
 static const int kVariantWaveN[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 32, 0, 0, 0, 0, 0, 0, 0,
-                                    80, 0, 64, 64, 0, 0, 0, 80, 64, 80, 64, 0, 0, 80, 80, 64, 112, 64, 80, 0, 80};
+                                    80, 0, 64, 64, 0, 0, 0, 80, 64, 80, 64, 0, 0, 80, 80, 64, 112, 64, 80, 0, 80, 80};
 int gemm_variant_wave_n(int variant) { return kVariantWaveN[variant]; }
 bool gemm_variant_coalesced(int variant) { return variant >= 18; }
 int gemm_num_variants() { return (int)(sizeof(kVariantTile) / sizeof(kVariantTile[0])); }
@@ -1718,6 +1971,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 27: return launch_epi<2, 2, 2, 5, 2, 1>(a, epi, s);
     case 28: return launch_epi<2, 2, 2, 4, 2, 1>(a, epi, s);
     case 31: return launch_epi<2, 4, 7, 5, 8, 1>(a, epi, s);
+    case 39:
+      if (gemm_kpair_eligible(a, epi)) return epi == EPI_RESID ? launch_kpair<EPI_RESID>(a, s) : launch_kpair<EPI_F32>(a, s);
+      [[fallthrough]];
     case 32: return launch_epi<4, 2, 4, 5, 8, 1>(a, epi, s);
     case 33: return launch_epi<2, 4, 8, 4, 8, 1>(a, epi, s);
     case 34: return launch_epi<2, 4, 4, 7, 8, 1>(a, epi, s);

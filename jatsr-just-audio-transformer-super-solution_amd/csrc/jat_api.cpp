@@ -349,6 +349,13 @@ static int pick_variant(int M, int N, int nbatch = 1) {
   // 36: the tile of 31 with the software-pipelined bf16 / GELU epilogue (JAT_EPI_PIPE=0 keeps the plain one: A/B)
   static const int epi_pipe = getenv("JAT_EPI_PIPE") ? atoi(getenv("JAT_EPI_PIPE")) : 1;
   if (epi_pipe && best == 31) best = 36;
+  // 39: the k-step-pair 224 x 160 tile for the N = 1280 class when it fills more of the chip than 256 x 160 (M = 7168: 256 tiles
+  // against 224); launch_gemm falls back to 32 for anything but the split-residual producer epilogues.  JAT_KPAIR=0: A/B
+  static const int kpair = getenv("JAT_KPAIR") ? atoi(getenv("JAT_KPAIR")) : 1;
+  if (kpair && best == 32 && nbatch == 1 && M % 224 == 0 && N % 160 == 0) {
+    auto eff = [](long t) { return (double)t / (double)(((t + 255) / 256) * 256); };
+    if (eff((long)(M / 224) * (N / 160)) > eff((long)((M + 255) / 256) * (N / 160))) best = 39;
+  }
   // 38: the persistent two-tile form of 36 (launch_gemm falls back to 36 for shapes / epilogues it does not take); JAT_PERSIST=0: A/B
   static const int persist = getenv("JAT_PERSIST") ? atoi(getenv("JAT_PERSIST")) : 1;
   if (persist && best == 36 && M % 224 == 0 && (long)(M / 224) * (N / 320) * nbatch > 256) best = 38;
@@ -856,7 +863,9 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
     auto var = [&](int site) { return m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, m->D); };
     const int np = m->D / gemm_variant_wave_n(var(G_OUT));
     sp->folded = fold_env > 0 && m->cfg.norm_mode == JAT_NORM_RMS_W && m->fold_src_ok && (np == 4 || np == 8 || np == 16) &&
-                 gemm_variant_coalesced(var(G_OUT)) && var(G_OUT) == var(G_FC2) && var(G_OUT) == var(G_OTHER) &&
+                 gemm_variant_coalesced(var(G_OUT)) && gemm_variant_coalesced(var(G_FC2)) && gemm_variant_coalesced(var(G_OTHER)) &&
+                 gemm_variant_wave_n(var(G_OUT)) == gemm_variant_wave_n(var(G_FC2)) &&
+                 gemm_variant_wave_n(var(G_OUT)) == gemm_variant_wave_n(var(G_OTHER)) &&
                  (M > kSplitMaxRows || fold_env >= 2);   // small-M buckets finish fc2 / out_proj with split-K instead (2: force, tests)
     const char* fuse_s = getenv("JAT_FUSE_QKV_ATTN");
     const int fuse_env = fuse_s ? atoi(fuse_s) : 1;

@@ -95,7 +95,7 @@ GEMM_SHAPES = [(128, 128, 64), (256, 512, 128), (1000, 1792, 1280), (56, 1536, 2
 
 # every live tile / pipeline variant of gemm.hip (ids are stable; the structures measured and retired in rounds 1-2 are
 # rejected by launch_gemm: test_retired_gemm_variants_are_rejected); JAT_TEST_VARIANTS="31,32" narrows the sweep
-LIVE_VARIANTS = [10, 18, 20, 21, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36, 38]
+LIVE_VARIANTS = [10, 18, 20, 21, 25, 26, 27, 28, 31, 32, 33, 34, 35, 36, 38, 39]
 GEMM_VARIANTS = [int(v) for v in os.environ.get("JAT_TEST_VARIANTS", "").split(",") if v] or LIVE_VARIANTS
 
 
@@ -177,6 +177,35 @@ def test_gemm_fold_producer(variant, M, N, K, ntok, epi):
     assert (got - ref).abs().max() <= 2 ** -15 * float(ref.abs().max()) + 1e-6
     # hi alone is x rounded to the operand dtype: it is the next GEMM's A operand as it stands
     assert ((hi.double() - ref).abs() <= 2 ** -8 * ref.abs() + 1e-6).all()
+    assert rel(part.double().sum(1), (ref * ref).sum(1)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,ntok", [(224, 160, 64, 128), (448, 1280, 128, 128), (448, 1280, 192, 23), (672, 320, 256, 345),
+                                        (7168, 1280, 1280, 128), (7168, 1280, 5120, 128)])
+@pytest.mark.parametrize("epi", [0, 3])
+def test_gemm_kpair_kernel(M, N, K, ntok, epi):
+    """Variant 39 (gemm_kpair_kernel: 224 x 160 tile, two wave groups on the two k-steps of every K-tile, three LDS stages,
+    partial accumulators exchanged through LDS) on the split-residual producer epilogues: against fp64, 1 / 2 / 3 / 4 / 20 / 80
+    K-tiles (every prologue and tail path), wave tiles inside one sample and across several; and deterministic."""
+    A, Af, W, Wf, bias, gate, hi0, lo0 = _fold_case(M, N, K, ntok, 240 + epi)
+    res = []
+    for _ in range(2):
+        hi, lo = hi0.clone(), lo0.clone()
+        part = torch.full((M, N // 80), float("nan"), device=A.device)
+        L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), None, M, N, K, epi, L.ptr(gate), N, ntok, L.ptr(hi),
+                                        L.ptr(lo), L.ptr(part), None, 0, 39, L.stream_ptr()))
+        torch.cuda.synchronize()
+        res.append((hi, lo, part))
+    assert all(torch.equal(a, b) for a, b in zip(*res))
+    hi, lo, part = res[0]
+    y = Af.double() @ Wf.double().T + bias.double()
+    if epi == 3:
+        bidx = torch.arange(M, device=A.device) // ntok
+        ref = (hi0.double() + lo0.double()) + gate.double()[bidx] * y
+    else:
+        ref = y
+    assert ((hi.double() + lo.double()) - ref).abs().max() <= 2 ** -15 * float(ref.abs().max()) + 1e-5
+    assert ((hi.double() - ref).abs() <= 2 ** -8 * ref.abs() + 1e-5).all()
     assert rel(part.double().sum(1), (ref * ref).sum(1)) < 1e-5
 
 

@@ -68,7 +68,7 @@ def resid(M, K, N=1280):
         return lambda: L.check(L.lib().jat_k_gemm_fold(L.ptr(A), L.ptr(W), L.ptr(bias), None, M, N, K, 3, L.ptr(gate), N, 128,
                                                        L.ptr(hi), L.ptr(lo), L.ptr(part), None, 0, v, L.stream_ptr()))
     cases = [("v32 K loop only", run(32), 1)]
-    for v in (32,):
+    for v in (32, 39):
         cases += [(f"v{v} split residual, no global stores", run(v), 128), (f"v{v} split residual (the sampler's form)", run(v), 0)]
     bench(cases, f"gated residual producer M={M} N={N} K={K}")
 
