@@ -81,9 +81,40 @@ def dry_run(args):
         dist.init_process_group("gloo")
     a, b = shard_range(args.B, world, rank) if args.scaling == "strong" else (0, args.B)
     x = np.ones((b - a, 64), np.float32)
+    metric, unit_per_step, scaling = "DiT latent-frames/sec (B=28,C=1024,T=512, 50-step CFG)", None, args.scaling
+    if args.mode == "train":
+        # the training step's only cross-rank traffic: the flat gradient buffer exchanged in slices (reduce-scatter + all-gather,
+        # jatsr_amd.dist.exchange_sum_) — here on a CPU stand-in, through the same function and the same slice walk
+        from jatsr_amd.dist import exchange_sum_
+        grads = torch.full((3 * (1 << 19) + 6,), float(rank + 1))      # slices of 2 MiB: above the exchange's all_reduce cut-over
+        metric, scaling = f"DiT training latent-frames/sec (B=28/GPU, C=1024, T={args.train_T})", "weak"
 
-    def step():
-        return float((x @ x.T).sum())
+        def step():
+            grads.fill_(float(rank + 1))
+            n, nsl = grads.numel(), 3
+            for sl in range(nsl):                              # slices as the backward hands them over
+                lo, hi = sl * (n // nsl), n if sl == nsl - 1 else (sl + 1) * (n // nsl)
+                for w in exchange_sum_(grads[lo:hi], async_op=True):
+                    w.wait()
+            assert float(grads[0]) == world * (world + 1) / 2 and float(grads[-1]) == world * (world + 1) / 2
+            return float((x @ x.T).sum())
+        unit_per_step = world * args.B * args.train_T
+    elif args.mode == "long":
+        # one long file: the chunk plan sharded round-robin over the ranks, one object gather per file (dist.sample_long_sharded)
+        from jatsr_amd.dist import sample_long_sharded
+        stride, chunk, ov = 1378 - 172, 1378, 172
+        nchunk = (args.long_T - ov + stride - 1) // stride
+        plan = [(i * stride, min(i * stride + chunk, args.long_T)) for i in range(nchunk)]
+        metric, scaling = f"DiT long-sequence latent-frames/sec (one file, T={args.long_T}, 50-step CFG)", "strong"
+
+        def step():
+            chunks = sample_long_sharded(lambda idxs: {i: torch.full((1, 4, plan[i][1] - plan[i][0]), float(i)) for i in idxs}, plan)
+            assert [c.shape[-1] for c in chunks] == [b_ - a_ for a_, b_ in plan] and all(float(c[0, 0, 0]) == i for i, c in enumerate(chunks))
+            return float(sum(c.shape[-1] for c in chunks))
+        unit_per_step = args.long_T
+    else:
+        def step():
+            return float((x @ x.T).sum())
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -100,12 +131,14 @@ def dry_run(args):
         dist.all_reduce(t)
         seen = int(t.item())
     total_b = args.B if args.scaling == "strong" else world * args.B
+    per_step = unit_per_step if unit_per_step is not None else total_b * args.T
     if rank == 0:
-        print(json.dumps({"metric": "DiT latent-frames/sec (B=28,C=1024,T=512, 50-step CFG)", "value": total_b * args.T * args.steps / elapsed,
+        print(json.dumps({"metric": metric, "value": per_step * args.steps / elapsed,
                           "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": seen,
-                          "config": {"workload": "launcher rehearsal on CPU (gloo), stand-in step", "B_local": b - a}}))
+                          "config": {"workload": f"launcher rehearsal on CPU (gloo), stand-in step, mode {args.mode}", "B_local": b - a,
+                                     "mode": args.mode}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -131,6 +164,10 @@ def main():
     ap.add_argument("--long-T", type=int, default=4096)
     ap.add_argument("--train-T", type=int, default=1378)
     ap.add_argument("--latent-loss", type=float, default=0.3, help="--mode train: latent perceptual loss weight (0 = MSE)")
+    ap.add_argument("--train-class", choices=["v3", "v2"], default="v3",
+                    help="--mode train: JaT_AudioSR_V3 (RMSNorm; train_ddp_v3m2.py) or JaT_AudioSR_V2 (LayerNorm; the class "
+                         "train_ddp_v3mod2.py:706 trains = BASELINE configs[3], with JAT_OPERAND_DTYPE=fp16 for its autocast dtype)")
+    ap.add_argument("--no-single-chunk", action="store_true", help="skip the B=1 single-chunk sampler legs")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: B per GPU fixed; strong: one batch of B sharded over the GPUs (dist.shard_range)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the launcher and timing contract (tests)")
@@ -201,21 +238,25 @@ def main():
         noise = [torch.from_numpy(recipe.gaussian("noise_long", (1, C_lat, b - a), i)).to(dev) for i, (a, b) in enumerate(plan)]
 
         def sample_chunks(idxs):
-            """This rank's chunks, batched into one launch (rows shorter than the longest one padded + key-masked)."""
+            """This rank's chunks: one launch per bucket of jatsr_amd.chunk_groups (normally ONE: rows shorter than the longest
+            chunk padded + key-masked; a 128-token bucket cannot mask keys, so there every length gets its own launch)."""
             if not idxs:
                 return {}
-            Tm = max(plan[i][1] - plan[i][0] for i in idxs)
-            lens = [plan[i][1] - plan[i][0] for i in idxs]
-            lrb = torch.zeros(len(idxs), C_lat, Tm, device=dev)
-            zb = torch.zeros(len(idxs), C_lat, Tm, device=dev)
-            for j, i in enumerate(idxs):
-                lrb[j, :, :lens[j]] = jatsr_amd.channel_affine(lr_long[None, :, plan[i][0]:plan[i][1]], mean, std)[0]
-                zb[j, :, :lens[j]] = noise[i][0]
-            use_lens = any(v != Tm for v in lens) and (Tm + 3) // 4 != 128
-            gen = jatsr_amd.flow_matching_sample(model, lrb, args.num_steps, args.cfg_scale, device=dev, verbose=False, z0=zb,
-                                                 lengths=lens if use_lens else None)
-            gen = jatsr_amd.channel_affine(gen, mean, std, inverse=True)
-            return {i: gen[j:j + 1, :, :lens[j]].contiguous() for j, i in enumerate(idxs)}
+            all_lens = [plan[i][1] - plan[i][0] for i in idxs]
+            out = {}
+            for Tm, members in jatsr_amd.chunk_groups(all_lens).items():
+                ids = [idxs[j] for j in members]
+                lens = [all_lens[j] for j in members]
+                lrb = torch.zeros(len(ids), C_lat, Tm, device=dev)
+                zb = torch.zeros(len(ids), C_lat, Tm, device=dev)
+                for j, i in enumerate(ids):
+                    lrb[j, :, :lens[j]] = jatsr_amd.channel_affine(lr_long[None, :, plan[i][0]:plan[i][1]], mean, std)[0]
+                    zb[j, :, :lens[j]] = noise[i][0]
+                gen = jatsr_amd.flow_matching_sample(model, lrb, args.num_steps, args.cfg_scale, device=dev, verbose=False, z0=zb,
+                                                     lengths=lens if any(v != Tm for v in lens) else None)
+                gen = jatsr_amd.channel_affine(gen, mean, std, inverse=True)
+                out.update({i: gen[j:j + 1, :, :lens[j]].contiguous() for j, i in enumerate(ids)})
+            return out
 
         def one_file():
             chunks = sample_long_sharded(sample_chunks, plan)
@@ -253,6 +294,13 @@ def main():
         from jatsr_amd.train import Trainer
         del sampler
         Tt = args.train_T
+        if args.train_class == "v2":      # the v3mod2 trainer's model class: LayerNorm without affine (train_ddp_v3mod2.py:706)
+            del model
+            torch.cuda.empty_cache()
+            sd2 = recipe.make_state_dict(cfg, "ln")
+            model = jatsr_amd.JaT_AudioSR_V2(**cfg, dropout=0.1, drop_path_rate=0.05)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()}, strict=False)
+            model = model.to(dev).eval()
         # JAT_OPERAND_DTYPE=fp16 python bench.py --mode train: the v3mod2 trainer's fp16 autocast + dynamic loss scale
         trainer = Trainer(model, batch_size=B, frames=Tt, seed=1 + rank, latent_loss_weight=args.latent_loss)
         hr_t = torch.from_numpy(recipe.gaussian("train_hr", (B, C_lat, Tt), 300 + rank)).to(dev)
@@ -278,10 +326,11 @@ def main():
                 "value": world * B * Tt * args.steps / elapsed, "unit": "latent-frames/s", "n_gpus": world,
                 "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": L.operand_dtype(), "data": "synthetic",
-                "config": {"workload": f"{args.config} DDP training step (MSE + {args.latent_loss} x latent perceptual loss, "
-                                       f"dropout 0.1, clip 1.0, AdamW), B={B}/GPU T={Tt}, flat-buffer gradient all-reduce "
+                "config": {"workload": f"{args.config} DDP training step, {'JaT_AudioSR_V2 (LayerNorm)' if args.train_class == 'v2' else 'JaT_AudioSR_V3 (RMSNorm)'}, "
+                                       f"{L.operand_dtype()} operands (MSE + {args.latent_loss} x latent perceptual loss, "
+                                       f"dropout 0.1, clip 1.0, AdamW), B={B}/GPU T={Tt}, flat-buffer gradient exchange "
                                        "over RCCL overlapped with the backward", "B_per_gpu": B, "T": Tt,
-                           "parallelism": f"dp{world}"},
+                           "parallelism": f"dp{world}", "model_class": "JaT_AudioSR_V2" if args.train_class == "v2" else "JaT_AudioSR_V3"},
                 "tflops_per_gpu": tfl, "mfma_frac": tfl / PEAK_BF16_TFLOPS, "loss": st["loss"], "grad_norm": st["grad_norm"]}))
         if dist is not None:
             dist.barrier()
@@ -350,6 +399,31 @@ def main():
                              "tflops": fwd_flops_B / (fwd_ms * 1e-3) / 1e12,
                              "mfma_frac": fwd_flops_B / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
 
+        # ---- the reference's own loop body: B = 1, one chunk per launch (infer_test_v3m2.py:370-398: a 16 s chunk = 1378 frames,
+        # CFG double batch -> M = 690 rows), and one 512-frame chunk for comparison with the headline's T
+        if not args.no_single_chunk and world == 1:
+            legs = {}
+            for Tc in (1378, 512):
+                lr1 = torch.from_numpy(recipe.gaussian("lr_chunk", (1, C_lat, Tc), 21)).to(dev)
+                z1 = torch.from_numpy(recipe.gaussian("z_chunk", (1, C_lat, Tc), 22)).to(dev)
+                s1 = jatsr_amd.Sampler(model, 1, Tc, args.num_steps, args.cfg_scale)
+                for _ in range(2):
+                    o1 = s1.run(lr1, z1)
+                torch.cuda.synchronize()
+                tc0 = time.perf_counter()
+                nrun = 5
+                for _ in range(nrun):
+                    o1 = s1.run(lr1, z1)
+                torch.cuda.synchronize()
+                tcs = (time.perf_counter() - tc0) / nrun
+                assert bool(torch.isfinite(o1).all())
+                fl1 = recipe.forward_flops(cfg, 1, Tc) * (2 if use_cfg else 1) * args.num_steps
+                legs[f"T{Tc}"] = {"ms": tcs * 1e3, "latent_frames_per_s": Tc / tcs, "tflops": fl1 / tcs / 1e12,
+                                  "mfma_frac": fl1 / tcs / 1e12 / PEAK_BF16_TFLOPS}
+                del s1
+            result["single_chunk"] = {"workload": f"B=1, one chunk per launch, {args.num_steps}-step CFG={args.cfg_scale}, hipGraph "
+                                                  "(T1378: the reference's 16 s chunk, M = 690 rows with CFG)", **legs}
+
         # ---- long-sequence chunked inference (BASELINE configs[4]): one file of T=4096 latent frames -> 4 chunks
         # (3 x 1378 + 478, overlap 172; infer_test_v3m2.py:340-404), equal-length chunks batched, 50-step CFG each
         if not args.no_long and world == 1:   # single-GPU diagnostics: not repeated in the N > 1 scaling runs
@@ -375,30 +449,38 @@ def main():
         # live: the same sampling run replayed eagerly with every fc1 launch bracketed by a HIP event pair on the
         # launch stream (jat_prof_*); rocprofv3 --kernel-trace --stats of this command must agree (profiles/).
         per_run_launches = cfg["depth"] * args.num_steps
-        L.check(L.lib().jat_prof_gemm_site(2, per_run_launches))
+        L.check(L.lib().jat_prof_gemm_site(model._get_handle().ptr, 2, per_run_launches))
         sampler.run(lr, z0, use_graph=False)
         torch.cuda.synchronize()
         tot_ms, n_l, fl, var = C.c_double(), C.c_int32(), C.c_double(), C.c_int32()
-        L.check(L.lib().jat_prof_collect(C.byref(tot_ms), C.byref(n_l), C.byref(fl), C.byref(var)))
+        L.check(L.lib().jat_prof_collect(model._get_handle().ptr, C.byref(tot_ms), C.byref(n_l), C.byref(fl), C.byref(var)))
         Mg = (2 if use_cfg else 1) * B * ((T + 3) // 4)
         Ng, Kg = int(cfg["hidden_size"] * cfg.get("mlp_ratio", 4.0)), cfg["hidden_size"]
         g_ms = tot_ms.value / max(n_l.value, 1)
         g_flops = fl.value / max(n_l.value, 1)
         ach = g_flops / (g_ms * 1e-3) / 1e12
-        traffic = None   # L2-miss bytes per launch from the committed PMC passes (same kernel, same shape), if any
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")))
-            traffic = pmc.get(f"fc1_variant{var.value}_M{Mg}_N{Ng}_K{Kg}", {}).get("traffic_bytes")
-        except Exception:
-            pass
-        result["roofline"] = {"kernel": f"gemm_bf16_kernel<...,EPI_BF16_GELU> tile variant {var.value} (MLP fc1) "
-                                        f"M={Mg} N={Ng} K={Kg}",
+        traffic, traffic_src, traffic_build_ok = None, None, None   # fabric-side bytes per launch from the committed PMC passes
+        import hashlib
+        lib_sha = hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]
+        for rnd in ("r03", "r02"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))
+            except Exception:
+                continue
+            ent = pmc.get(f"fc1_variant{var.value}_M{Mg}_N{Ng}_K{Kg}")
+            if ent:
+                traffic, traffic_src = ent.get("traffic_bytes"), f"profiles/{rnd}/pmc_traffic.json"
+                traffic_build_ok = pmc.get("_lib_sha256_16") == lib_sha if pmc.get("_lib_sha256_16") else None
+                break
+        kname = "gemm_persist_kernel<2,4,7,5,EPI_BF16_GELU> (two 224x320 tiles per CU)" if var.value == 38 else "gemm_bf16_kernel<...,EPI_BF16_GELU>"
+        result["roofline"] = {"kernel": f"{kname} tile variant {var.value} (MLP fc1) M={Mg} N={Ng} K={Kg}",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                               "traffic_note": "bytes/launch = (2*FETCH_SIZE+WRITE_SIZE)*1024 of THIS kernel variant and shape from "
-                                              "profiles/r02/pmc_traffic.json (separate rocprofv3 --pmc passes of this build, "
-                                              "tools/pmc_traffic.sh; fabric-side: Infinity-Cache hits included); null if the "
-                                              "variant/shape has no committed pass",
+                                              f"{traffic_src} (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh; fabric-side: "
+                                              "Infinity-Cache hits included); null if the variant/shape has no committed pass; "
+                                              "traffic_same_build: the committed passes were taken with this very libjat_hip.so",
+                              "traffic_same_build": traffic_build_ok, "lib_sha256_16": lib_sha,
                               "flops_per_launch": g_flops, "avg_launch_ms": g_ms, "launches_timed": n_l.value}
 
         # ---- training step (BASELINE configs[3]; train_ddp_v3m2.py:533-622): forward + MSE + backward + clip + AdamW on
@@ -430,10 +512,33 @@ def main():
                                   "workspace_GB": trainer.workspace_bytes() / 1e9}
                 del trainer, hr_t, lr_t
                 torch.cuda.empty_cache()
+            # configs[3] as the reference runs it: JaT_AudioSR_V2 (LayerNorm) + MSE + latent perceptual loss under fp16 autocast with a
+            # dynamic loss scale (train_ddp_v3mod2.py:706,745,854-896).  The operand dtype is a process-level choice (libjat_hip_fp16.so):
+            # a CHILD process (this one keeps its GPU context; nothing is exec'ed) runs `bench.py --mode train --train-class v2`.
+            import subprocess
+            env = dict(os.environ, JAT_OPERAND_DTYPE="fp16")
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--train-class", "v2", "--train-T", "1378",
+                   "--latent-loss", "0.3", "--steps", "5", "--warmup", "2", "--B", str(B)]
+            try:
+                cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+                if cp.returncode == 0 and line:
+                    ch = json.loads(line[-1])
+                    legs["T1378_v3mod2_V2_latent_loss_fp16"] = {"ms_per_step": ch["ms_per_step"], "latent_frames_per_s": ch["value"],
+                                                               "tflops": ch["tflops_per_gpu"], "mfma_frac": ch["mfma_frac"],
+                                                               "loss": ch["loss"], "grad_norm": ch["grad_norm"], "dtype": ch["dtype"],
+                                                               "model_class": ch["config"]["model_class"]}
+                else:
+                    legs["T1378_v3mod2_V2_latent_loss_fp16"] = {"error": (cp.stderr or cp.stdout)[-400:]}
+            except Exception as ex:   # the headline line must not die with a diagnostics leg
+                legs["T1378_v3mod2_V2_latent_loss_fp16"] = {"error": repr(ex)[:400]}
             result["train_step"] = {"workload": f"{args.config} bf16 training step B={B}/GPU (fwd + MSE + bwd + "
                                                 "clip_grad_norm 1.0 + AdamW), dropout 0.1 / DropPath 0..0.05 "
-                                                "as train_ddp_v3m2.py:82-83; *_latent_loss: MSE + 0.3 x latent "
-                                                "perceptual loss of train_ddp_v3mod2.py (configs[3]); one GPU", **legs}
+                                                "as train_ddp_v3m2.py:82-83 (JaT_AudioSR_V3, bf16 operands: the V3-class trainers); "
+                                                "*_latent_loss: + 0.3 x latent perceptual loss; T1378_v3mod2_V2_latent_loss_fp16: "
+                                                "BASELINE configs[3] as the reference runs it — JaT_AudioSR_V2 (LayerNorm), MSE + latent "
+                                                "loss, fp16 operands + dynamic loss scale (train_ddp_v3mod2.py:706,745,854-896), child "
+                                                "process on libjat_hip_fp16.so; one GPU", **legs}
 
         # ---- CPU baseline: the numpy oracle (port of the reference's fp32 CPU forward, pinned to the
         # reference by tests/golden) on this host's cores: 1 warm-up + 3 timed forwards at B=28, T=512, and the oracle's
@@ -445,7 +550,20 @@ def main():
                 avail = len(os.sched_getaffinity(0))
             except AttributeError:
                 avail = os.cpu_count() or 1
-            cores = min(avail, 32)     # BLAS threads actually used (beyond 32 the fp32 GEMMs of this size only oversubscribe)
+            # BLAS thread count: BASELINE.md asks for the node's host cores; more threads are not faster for fp32 GEMMs of this size
+            # (M = B * 128 rows), so a short sweep on a B = 4 forward picks the count and the sweep travels in the JSON.
+            orc_s = O.OracleModel(cfg, sd, "rms", np.float32)
+            xs4, xc4 = recipe.make_latents(4, C_lat, T, salt=4)
+            t4 = np.linspace(0.1, 0.9, 4).astype(np.float32)
+            sweep = {}
+            for nthr in sorted({min(avail, n) for n in (16, 32, 64, 128, avail)}):
+                threadpool_limits(limits=nthr)
+                orc_s.forward(xs4, t4, xc4)
+                w0 = time.perf_counter()
+                orc_s.forward(xs4, t4, xc4)
+                sweep[nthr] = time.perf_counter() - w0
+            cores = min(sweep, key=sweep.get)
+            del orc_s
             threadpool_limits(limits=cores)
             cpu_model = "unknown"
             try:
@@ -478,6 +596,7 @@ def main():
             result["cpu_baseline"] = {
                 "value": smp_fps, "unit": "latent-frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
                 "host_cores_available": avail,
+                "thread_sweep_s_per_B4_forward": {str(k): round(v, 3) for k, v in sweep.items()},
                 "sample": f"oracle 50-step CFG={args.cfg_scale} sampler at B=2,T={T}: first {box_steps} of {args.num_steps} "
                           f"Euler steps timed ({s_s:.2f} s per step, CFG double batch) and scaled to the full run "
                           f"(time-boxed: a complete CPU run is ~{s_s * args.num_steps / 60 * 14:.0f} min at B=28); "

@@ -74,6 +74,11 @@ void jat_model_destroy(jat_model* m);
  * LN_NOAFFINE mode. */
 int jat_model_load_weights(jat_model* m, const jat_tensor_ref* named, int32_t n, void* stream);
 int jat_model_workspace_bytes(const jat_model* m, int32_t B, int32_t T, size_t* out);
+/* Behaviour switches of this handle.  Their defaults come from the JAT_* environment variables, which are read ONCE, in
+ * jat_model_create (INTEGRATION.md "Environment switches"); nothing on the enqueue path reads the environment.  Names:
+ * "fuse_qkv_attn" (0 / 1 / 2), "qkv_split", "fuse_finish", "fold_norm" (0 / 1 / 2), "split_patch", "gemm_dbg", "fold_cap_mb".
+ * Takes effect for forwards enqueued and samplers created afterwards. */
+int jat_model_set_switch(jat_model* m, const char* name, int32_t value);
 
 /* == JaT_AudioSR_V3.forward(x_t, t, x_cond) in eval mode (jat_audiosr_v3.py:422-471).
  * x_t, x_cond, x_pred: [B, input_channels, T]; t: [B].  Pads T to a multiple of 4 internally (:435-439),
@@ -238,12 +243,13 @@ int jat_k_recon_loss(const float* pred, const float* target, float* dpred, float
 int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 
 /* ---- measurement aid (bench.py roofline leg; no reference counterpart) ------------------------------------ */
-/* Bracket every GEMM launch of one call site (0 qkv, 1 out_proj, 2 MLP fc1, 3 MLP fc2, 4 other; -1 = off) with a
+/* (state lives in the model handle: two models in one process do not share a bracket)
+ * Bracket every GEMM launch of one call site (0 qkv, 1 out_proj, 2 MLP fc1, 3 MLP fc2, 4 other; -1 = off) with a
  * HIP event pair on the launch stream, for at most max_launches launches.  Eager calls only. */
-int jat_prof_gemm_site(int32_t site, int32_t max_launches);
+int jat_prof_gemm_site(jat_model* m, int32_t site, int32_t max_launches);
 /* Sum of the bracketed launch durations [host ms], their count, algorithmic FLOPs and the tile variant used;
  * synchronises on the recorded events and switches the bracket off. */
-int jat_prof_collect(double* total_ms, int32_t* launches, double* flops, int32_t* variant);
+int jat_prof_collect(jat_model* m, double* total_ms, int32_t* launches, double* flops, int32_t* variant);
 
 #ifdef __cplusplus
 }

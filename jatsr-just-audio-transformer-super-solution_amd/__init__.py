@@ -12,7 +12,7 @@ from . import recipe  # noqa: F401  (numpy only)
 _LAZY = {
     "JaT_AudioSR_V3": "model", "JaT_AudioSR_V2": "model", "DiTBlock_GQA": "model",
     "GroupedQueryAttention": "model", "load_model": "model",
-    "flow_matching_sample": "sampler", "crossfade_chunks": "sampler", "chunk_plan": "sampler",
+    "flow_matching_sample": "sampler", "crossfade_chunks": "sampler", "chunk_plan": "sampler", "chunk_groups": "sampler",
     "sample_long": "sampler", "Sampler": "sampler", "channel_affine": "sampler",
     "load_latent_file": "io", "save_latent_file": "io", "load_stats": "io",
     "Trainer": "train", "u_shaped_timestep_sampling": "train", "get_lr": "train", "GradScaler": "train",

@@ -41,6 +41,7 @@ SIGNATURES = {
     "jat_model_create": (C.c_int, [C.POINTER(JatConfig), C.POINTER(_VP)]),
     "jat_model_destroy": (None, [_VP]),
     "jat_model_load_weights": (C.c_int, [_VP, C.POINTER(JatTensorRef), _I32, _VP]),
+    "jat_model_set_switch": (C.c_int, [_VP, C.c_char_p, _I32]),
     "jat_model_workspace_bytes": (C.c_int, [_VP, _I32, _I32, C.POINTER(_SZ)]),
     "jat_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP, _SZ, _VP]),
     "jat_block_forward": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I32, _I32, _VP, _SZ, _VP]),
@@ -76,8 +77,8 @@ SIGNATURES = {
     "jat_trainer_loss_terms": (C.c_int, [_VP, _VP, _VP]),
     "jat_trainer_fwd_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F32, C.c_uint64, _VP, _VP, _VP]),
     "jat_trainer_optim": (C.c_int, [_VP, _F32, _F32, _F32, _F32, _F32, _F32, _F32, _I32, _VP, _VP]),
-    "jat_prof_gemm_site": (C.c_int, [_I32, _I32]),
-    "jat_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),
+    "jat_prof_gemm_site": (C.c_int, [_VP, _I32, _I32]),
+    "jat_prof_collect": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),
 }
 
 GRAD_HOOK = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)   # jat_trainer_set_grad_hook callback

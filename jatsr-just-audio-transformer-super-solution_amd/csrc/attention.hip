@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
   const int frow = lane & 15, fg = lane >> 4;
   const int hk = blockIdx.x, b = blockIdx.y;
   const int G = p.Hq / p.Hkv, N = p.N;
+  const int Nk = p.lens ? min(p.lens[b], N) : N;   // keys this sample attends to (a short chunk padded into a longer bucket)
   const int q0 = wave * (16 * QT);
   const bf16_t* kbase = p.k + (int64_t)b * N * p.ldk + hk * 64;
   const bf16_t* vbase = p.vt + ((int64_t)(b * p.Hkv + hk) * 64) * p.npad;
@@ -291,12 +292,12 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
     float linv[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      if (N < KVB) {  // wave-uniform: mask the padded keys only when there are any
+      if (Nk < KVB) {  // block-uniform: mask the padded keys only when there are any
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r >= N) st[qt][kt][r] = -1e30f;
+            if (32 * (kt >> 1) + 8 * fg + 4 * (kt & 1) + r >= Nk) st[qt][kt][r] = -1e30f;
       }
       float mx = -1e30f;
 #pragma unroll
@@ -371,7 +372,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid((a.N + 64 * QT - 1) / (64 * QT), a.Hq, a.B);
   static const int kvb_env = getenv("JAT_ATTN_KVB") ? atoi(getenv("JAT_ATTN_KVB")) : 64;
   static const int group_env = getenv("JAT_ATTN_GROUP") ? atoi(getenv("JAT_ATTN_GROUP")) : 1;
-  if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse && !a.drop.thresh && !a.lens) {   // the sampler's shape: K/V staged once per KV head
+  if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse && !a.drop.thresh) {   // the sampler's shape: K/V staged once per KV head (lens honoured)
     hipLaunchKernelGGL((attn_group_kernel<1, 8>), dim3(a.Hkv, a.B), dim3(512), 0, s, a);
   } else if (kvb_env == 64 || a.N <= 64) {
     hipLaunchKernelGGL((attn_fwd_kernel<QT, 64>), grid, dim3(256), 0, s, a);

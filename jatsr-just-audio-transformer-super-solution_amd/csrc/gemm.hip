@@ -1636,6 +1636,10 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   static_assert(PIECES % NW == 0, "every wave issues the same number of DMA pieces");
   static_assert(EPI == EPI_RESID || EPI == EPI_F32, "split-residual producer epilogues");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef JAT_TIMELINE
+  unsigned long long tl_[7] = {0, 0, 0, 0, 0, 0, 0}, tlx_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  JAT_TL(0) JAT_TLR(5)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wq = wave & 3, wm = wq >> 1, wn = wq & 1;
@@ -1696,6 +1700,10 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
+  JAT_TL(1)
+  // (All CP pieces go out in the load phase.  Spreading half of them between the MFMAs of the compute phase was measured SLOWER,
+  // 1420 -> 1570 cycles per K-tile: the tile needs 44 B/clk of the ~46 B/clk the per-CU L2->LDS path delivers, and a DMA that
+  // stalls at issue inside the compute phase stalls the MFMAs behind it.)
   for (int kt = 0; kt < nk; ++kt) {
     // load phase of K-tile kt (my pieces of K-tile kt+1 were waited for at the end of the previous load phase)
     rd(kt);
@@ -1717,6 +1725,7 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   }
+  JAT_TL(2)
   if (grp == 0) __builtin_amdgcn_s_barrier();
   // ---- exchange: every wave is past its last fragment read (the barrier above) -------------------------------------------
   // slot (wq, direction): group 1 -> group 0 row tiles 0..3 (20 accumulator tiles), group 0 -> group 1 row tiles 4..6 (15)
@@ -1750,7 +1759,8 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // the exchange buffers are consumed: the slabs below may overwrite them
-  if (p.dbg & 1) return;
+  JAT_TL(3)
+  if (p.dbg & 1) { JAT_TL_FLUSH() return; }
   // ---- split-residual epilogue (see gemm_bf16_kernel) on my half: row tiles [I0, I0 + NT) of the wave tile ---------------------
   constexpr int RS = TN * 64 + 16, CPR8 = TN * 2, NCH8 = TN;
   static_assert(NW * 32 * RS <= 3 * STAGE, "epilogue slabs fit the stages");
@@ -1843,6 +1853,7 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   };
   if (grp == 0) half_epilogue(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
   else half_epilogue(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+  JAT_TL_FLUSH()
 }
 
 static bool gemm_kpair_eligible(const GemmArgs& a, int epi) {

@@ -105,6 +105,11 @@ extern "C" int jat_model_create(const jat_config* c, jat_model** out) {
   m->kvD = m->Hkv * HEAD_DIM; m->mlp = c->mlp_hidden; m->bott = c->bottleneck_dim;
   m->Cin = c->input_channels; m->Cc = c->cond_channels; m->P = 4;
   m->Kp = m->P * (m->Cin + m->Cc); m->Fout = m->P * m->Cin;
+  auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  m->sw.fuse_qkv_attn = env_int("JAT_FUSE_QKV_ATTN", 1); m->sw.qkv_split = env_int("JAT_QKV_SPLIT", 1);
+  m->sw.fuse_finish = env_int("JAT_FUSE_FINISH", 1); m->sw.fold_norm = env_int("JAT_FOLD_NORM", 1);
+  m->sw.split_patch = env_int("JAT_SPLIT_PATCH", 1); m->sw.gemm_dbg = env_int("JAT_GEMM_DBG", 0);
+  m->sw.fold_cap_mb = env_int("JAT_FOLD_CAP_MB", 0);
   if (const char* v = getenv("JAT_GEMM_VARIANT"))
     for (int i = 0; i < 5; ++i) m->variants[i] = atoi(v);
   if (const char* v = getenv("JAT_GEMM_VARIANTS")) {  // "qkv,out,fc1,fc2,other"
@@ -116,8 +121,20 @@ extern "C" int jat_model_create(const jat_config* c, jat_model** out) {
   return JAT_OK;
 }
 
+extern "C" int jat_model_set_switch(jat_model* m, const char* name, int32_t value) {
+  if (!m || !name) return fail(JAT_E_INVALID, "null argument");
+  const std::string n(name);
+  int* slot = n == "fuse_qkv_attn" ? &m->sw.fuse_qkv_attn : n == "qkv_split" ? &m->sw.qkv_split : n == "fuse_finish" ? &m->sw.fuse_finish
+            : n == "fold_norm" ? &m->sw.fold_norm : n == "split_patch" ? &m->sw.split_patch : n == "gemm_dbg" ? &m->sw.gemm_dbg
+            : n == "fold_cap_mb" ? &m->sw.fold_cap_mb : nullptr;
+  if (!slot) return fail(JAT_E_INVALID, "unknown switch '%s'", name);
+  *slot = value;
+  return JAT_OK;
+}
+
 extern "C" void jat_model_destroy(jat_model* m) {
   if (!m) return;
+  for (hipEvent_t e : m->prof.ev) (void)hipEventDestroy(e);
   if (m->blob) (void)hipFree(m->blob);
   delete m;
 }
@@ -307,13 +324,6 @@ extern "C" int jat_model_workspace_bytes(const jat_model* m, int32_t B, int32_t 
 // ---------------------------------------------------------------------------------------------------------
 // forward pieces
 // ---------------------------------------------------------------------------------------------------------
-struct GemmProf {
-  int site = -1, n = 0, variant = -1;
-  double flops = 0.0;
-  hipStream_t stream = nullptr;
-  std::vector<hipEvent_t> ev;
-};
-static GemmProf g_prof;
 
 // Tile choice by shape (gemm.hip variant table; measured on MI355X, profiles/r01/gemm_variants.md).  What
 // decides is how the tile count quantises onto 256 CUs (one 8-wave block or two 4-wave blocks per CU) and how
@@ -374,18 +384,17 @@ int jat_gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const b
   if (N % kTileN(variant) != 0) variant = 20;  // 128 x 128, always valid
   if (a.fold_out) { a.fold_np = N / gemm_variant_wave_n(variant); m->last_fold_np = a.fold_np; }
   if (a.rs_part) a.rs_np = m->last_fold_np;
-  static const int dbg_env = getenv("JAT_GEMM_DBG") ? atoi(getenv("JAT_GEMM_DBG")) : 0;  // profiling aid
-  a.dbg = dbg_env;
+  a.dbg = m->sw.gemm_dbg;   // profiling aid (0 in production)
   // measurement aid (bench.py roofline leg): bracket the launches of one call site with HIP events on the
   // launch stream.  Never active during graph capture (the bench enables it around eager forwards only).
-  const bool timed = g_prof.site == site && g_prof.n < (int)g_prof.ev.size() / 2;
-  if (timed) { g_prof.stream = s; (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s); }
+  const bool timed = m->prof.site == site && m->prof.n < (int)m->prof.ev.size() / 2;
+  if (timed) { m->prof.stream = s; (void)hipEventRecord(m->prof.ev[2 * m->prof.n], s); }
   hipError_t e = launch_gemm(a, epi, variant, s);
   if (timed) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
-    g_prof.flops += 2.0 * M * N * K;
-    g_prof.variant = variant;
-    ++g_prof.n;
+    (void)hipEventRecord(m->prof.ev[2 * m->prof.n + 1], s);
+    m->prof.flops += 2.0 * M * N * K;
+    m->prof.variant = variant;
+    ++m->prof.n;
   }
   if (e != hipSuccess) return fail(JAT_E_HIP, "gemm launch (M=%d N=%d K=%d epi=%d): %s", M, N, K, epi, hipGetErrorString(e));
   return JAT_OK;
@@ -438,8 +447,7 @@ static int resid_split(const jat_model* m, const Workspace& w, int site, int M, 
 // K-slices for the QKV GEMM of a small bucket (M <= kSplitMaxRows, un-folded, separate attention kernel): its 56 tiles at one
 // chunk leave 200 CUs without weights to pull; the slices are summed, rotated and laid out by splitk_qkv_finish_kernel
 static int qkv_split(const jat_model* m, const Workspace& w, int M, int K, bool folding) {
-  const char* on_s = getenv("JAT_QKV_SPLIT");   // read per call: tests A/B the two forms in one process
-  if ((on_s && atoi(on_s) == 0) || m->D % 64 != 0 || m->kvD % 64 != 0 || !w.kpart || folding || M > kSplitMaxRows || m->variants[G_QKV] >= 0) return 1;
+  if (!m->sw.qkv_split || m->D % 64 != 0 || m->kvD % 64 != 0 || !w.kpart || folding || M > kSplitMaxRows || m->variants[G_QKV] >= 0) return 1;
   const int N = m->D + 2 * m->kvD;
   int bm, bn;
   const int v = pick_variant(M, N);
@@ -461,11 +469,9 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
   const int D = m->D, M = B * ntok, Nqkv = D + 2 * m->kvD;
   const LayerW& L = m->layers[l];
   if (next_done) *next_done = false;
-  const char* fuse_s2 = getenv("JAT_FUSE_FINISH");   // read per call: tests A/B the two forms in one process
-  const bool can_fuse = !(fuse_s2 && atoi(fuse_s2) == 0) && splitk_resid_norm_supported(D);
+  const bool can_fuse = m->sw.fuse_finish && splitk_resid_norm_supported(D);
   if (!f && !xn_ready) KCHK(launch_norm_modulate(w.x, L.norm1, mod_l + 0 * D, mod_l + 1 * D, bstride, w.xn, M, D, ntok, m->cfg.norm_mode, s));
-  const char* fuse_s = getenv("JAT_FUSE_QKV_ATTN");  // read per call so that tests can A/B the two paths in one process
-  const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
+  const int fuse_env = m->sw.fuse_qkv_attn;   // per-handle switch (jat_model_set_switch): tests A/B the two paths on one model
   // one block per (sample, KV group): worth it only when B * Hkv blocks fill the 256 CUs (measured: +1.8 % at
   // B = 56, -5 % at B = 28); fuse_env = 2 forces it (tests).  With folded weights the sampler decided at creation.
   const bool fused_attn = f ? f->wqkv_g != nullptr
@@ -477,8 +483,7 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     a.out = w.ao; a.ldo = D; a.ntok = ntok; a.rope_inv_freq = m->rope_invf;
     a.attn_scale_log2e = 0.125f * 1.4426950408889634f;
     if (f) { a.rs_part = w.part; a.rs_np = m->last_fold_np; a.bias = f->bq_g + (int64_t)l * Nqkv; }
-    static const int dbg_env = getenv("JAT_GEMM_DBG") ? atoi(getenv("JAT_GEMM_DBG")) : 0;  // profiling aid (read once)
-    a.dbg = dbg_env;
+    a.dbg = m->sw.gemm_dbg;   // profiling aid (0 in production)
     KCHK(launch_qkv_attn(a, s));
   } else {
     GemmArgs e{};
@@ -764,12 +769,28 @@ static int fold_alloc(FoldTable& ft, void** p, size_t bytes) {
   ft.allocs.push_back(*p);
   return JAT_OK;
 }
+static int build_fold_table_impl(jat_model* m, FoldTable& ft, int steps, const float* mod, bool group_major, bf16_t* sh_bf16,
+                                 hipStream_t s, bool need_w1, bool need_qkv);
 static int build_fold_table(jat_model* m, FoldTable& ft, int steps, const float* mod, bool group_major, bf16_t* sh_bf16,
                             hipStream_t s) {
-  const int D = m->D, kvD = m->kvD, mlp = m->mlp, depth = m->depth, Nqkv = D + 2 * kvD;
-  const int64_t mrow = (int64_t)depth * 6 * D;
   const bool need_w1 = ft.w1 == nullptr;
   const bool need_qkv = group_major ? ft.qkv_g == nullptr : ft.qkv_i == nullptr;
+  const size_t keep = ft.allocs.size();
+  const int rc = build_fold_table_impl(m, ft, steps, mod, group_major, sh_bf16, s, need_w1, need_qkv);
+  if (rc != JAT_OK) {
+    // undo THIS call's allocations and pointers: what earlier calls built (and other samplers hold) stays valid, and no
+    // half-built part is left looking finished
+    (void)hipStreamSynchronize(s);
+    while (ft.allocs.size() > keep) { (void)hipFree(ft.allocs.back()); ft.allocs.pop_back(); }
+    if (need_w1) { ft.w1 = nullptr; ft.bf = nullptr; ft.wfinal = nullptr; }
+    if (need_qkv) { if (group_major) { ft.qkv_g = nullptr; ft.bq_g = nullptr; } else { ft.qkv_i = nullptr; ft.bq_i = nullptr; } }
+  }
+  return rc;
+}
+static int build_fold_table_impl(jat_model* m, FoldTable& ft, int steps, const float* mod, bool group_major, bf16_t* sh_bf16,
+                                 hipStream_t s, bool need_w1, bool need_qkv) {
+  const int D = m->D, kvD = m->kvD, mlp = m->mlp, depth = m->depth, Nqkv = D + 2 * kvD;
+  const int64_t mrow = (int64_t)depth * 6 * D;
   if (need_w1) {
     JCHK(fold_alloc(ft, (void**)&ft.w1, (size_t)steps * depth * mlp * D * 2));
     JCHK(fold_alloc(ft, (void**)&ft.bf, (size_t)steps * depth * mlp * 4));
@@ -856,7 +877,7 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   const size_t o_z = take(lat), o_lr = take(lat), o_xp = take((size_t)sp->Bf * m->Cin * T * 4);
   const size_t o_tab = take((size_t)steps * row * 4), o_ts = take((size_t)steps * 4), o_ws = take(ws_bytes);
   // Norm folding (default on for RMSNorm models; JAT_FOLD_NORM=0 keeps the norm kernels): decided per sampler.
-  const int fold_env = getenv("JAT_FOLD_NORM") ? atoi(getenv("JAT_FOLD_NORM")) : 1;
+  const int fold_env = m->sw.fold_norm;
   {  // the consumer side reads the row partials lane-linear: needs 4, 8 or 16 slots per row; the three producers of the
      // residual stream (patch embed, out_proj, fc2: all [M, D]) must agree on the slot count
     const int M = sp->Bf * ntok;
@@ -867,8 +888,7 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
                  gemm_variant_wave_n(var(G_OUT)) == gemm_variant_wave_n(var(G_FC2)) &&
                  gemm_variant_wave_n(var(G_OUT)) == gemm_variant_wave_n(var(G_OTHER)) &&
                  (M > kSplitMaxRows || fold_env >= 2);   // small-M buckets finish fc2 / out_proj with split-K instead (2: force, tests)
-    const char* fuse_s = getenv("JAT_FUSE_QKV_ATTN");
-    const int fuse_env = fuse_s ? atoi(fuse_s) : 1;
+    const int fuse_env = m->sw.fuse_qkv_attn;
     sp->fused_attn = fuse_env && m->Hq / m->Hkv == 5 && !m->group_copy_stale && ntok == 128 && (sp->Bf * m->Hkv >= 192 || fuse_env == 2);
   }
   const size_t o_sh = take((size_t)steps * m->D * 2);
@@ -882,8 +902,7 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   bf16_t* sh_bf16 = (bf16_t*)(sp->blob + o_sh);
   sp->lens_dev = (int*)(sp->blob + o_lens);
   sp->frames_dev = (int*)(sp->blob + o_frames);
-  static const int split_env = getenv("JAT_SPLIT_PATCH") ? atoi(getenv("JAT_SPLIT_PATCH")) : 1;
-  if (sp->use_cfg && split_env) sp->pc = (float*)(sp->blob + o_pc);
+  if (sp->use_cfg && m->sw.split_patch) sp->pc = (float*)(sp->blob + o_pc);
 
   int rc = JAT_OK;
   auto bail = [&](int code) { jat_sampler_destroy(sp); return code; };
@@ -900,11 +919,20 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
     if ((rc = adaln_path(m, wt.t_silu, sp->mod_table, steps, 0, m->depth, s)) != JAT_OK) return bail(rc);
     if (sp->folded) {
       // per-step folded weights: shared by every sampler of this model with the same step count (model-level cache)
+      // The cache keeps at most TWO step counts alive on its own (a table is ~0.5 GB per step for v3mod2: 25 GB at 50 steps,
+      // 50 GB at the 100 steps the reference README also offers); tables that a live sampler still holds stay until it is destroyed.
+      for (auto it = m->fold_cache.begin(); it != m->fold_cache.end() && m->fold_cache.size() >= 2;)
+        it = (it->first != steps && it->second.use_count() == 1) ? m->fold_cache.erase(it) : std::next(it);
+      const size_t Nq = (size_t)m->D + 2 * m->kvD;
+      const size_t need = (size_t)steps * m->depth * ((Nq + m->mlp) * m->D * 2 + (Nq + m->mlp) * 4) + (size_t)m->Fout * m->D * 2;
+      const bool over_cap = m->sw.fold_cap_mb > 0 && need > (size_t)m->sw.fold_cap_mb * 1048576;   // "fold_cap_mb": operator's bound
       std::shared_ptr<FoldTable>& slot = m->fold_cache[steps];
       if (!slot) slot = std::make_shared<FoldTable>();
-      if (build_fold_table(m, *slot, steps, sp->mod_table, sp->fused_attn, sh_bf16, s) != JAT_OK) {
+      if (over_cap || build_fold_table(m, *slot, steps, sp->mod_table, sp->fused_attn, sh_bf16, s) != JAT_OK) {
         (void)hipStreamSynchronize(s);
-        m->fold_cache.erase(steps);   // e.g. out of memory: run this sampler with the norm kernels
+        // over the cap or out of memory: run this sampler with the norm kernels.  What was already built stays for the samplers
+        // that hold it; an EMPTY entry is dropped so that a later, smaller request starts clean
+        if (!slot->w1 && !slot->qkv_g && !slot->qkv_i) m->fold_cache.erase(steps);
         sp->folded = false;
       } else {
         sp->fold = slot;
@@ -960,7 +988,7 @@ extern "C" int jat_sampler_set_lengths(jat_sampler* sp, const int32_t* frames, i
     if (frames[b] <= 0 || frames[b] > sp->T) return fail(JAT_E_INVALID, "length %d of row %d outside (0, %d]", frames[b], b, sp->T);
     tok[b] = (frames[b] + 3) / 4;                       // the reference pads a chunk to a multiple of 4 frames (:435-439)
     if (sp->use_cfg) tok[sp->B + b] = tok[b];           // CFG double batch [cond ; uncond]
-    all_full = all_full && tok[b] == ntok;
+    all_full = all_full && frames[b] == sp->T;          // per FRAME: the fused buckets wire no frame mask into patchify either
   }
   if (sp->fused_attn && !all_full)
     return fail(JAT_E_STATE, "this bucket runs the fused QKV+attention kernel (128 tokens), which has no key mask");
@@ -1092,45 +1120,47 @@ extern "C" int jat_k_attention(const uint16_t* q, const uint16_t* k, const uint1
   KCHK(launch_attention(a, (hipStream_t)stream));
   return JAT_OK;
 }
-extern "C" int jat_prof_gemm_site(int32_t site, int32_t max_launches) {
+extern "C" int jat_prof_gemm_site(jat_model* m, int32_t site, int32_t max_launches) {
+  if (!m) return fail(JAT_E_INVALID, "null model");
   if (site < -1 || site > G_OTHER) return fail(JAT_E_INVALID, "site must be -1 (off) or 0..4");
-  g_prof.site = site; g_prof.n = 0; g_prof.flops = 0.0; g_prof.variant = -1;
-  while ((int)g_prof.ev.size() < 2 * max_launches) {
+  m->prof.site = site; m->prof.n = 0; m->prof.flops = 0.0; m->prof.variant = -1;
+  while ((int)m->prof.ev.size() < 2 * max_launches) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
-    g_prof.ev.push_back(e);
+    m->prof.ev.push_back(e);
   }
   return JAT_OK;
 }
-extern "C" int jat_prof_collect(double* total_ms, int32_t* launches, double* flops, int32_t* variant) {
+extern "C" int jat_prof_collect(jat_model* m, double* total_ms, int32_t* launches, double* flops, int32_t* variant) {
+  if (!m) return fail(JAT_E_INVALID, "null model");
   double tot = 0.0;
-  for (int i = 0; i < g_prof.n; ++i) {
-    HIPCHK(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+  for (int i = 0; i < m->prof.n; ++i) {
+    HIPCHK(hipEventSynchronize(m->prof.ev[2 * i + 1]));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, m->prof.ev[2 * i], m->prof.ev[2 * i + 1]));
     tot += ms;
   }
   // calibrate: an EMPTY event pair on the same stream measures the marker-to-marker overhead the bracket adds to
   // every launch; subtract it so that the mean agrees with the rocprofv3 kernel-trace duration
-  if (g_prof.n > 0 && g_prof.ev.size() >= 2) {
+  if (m->prof.n > 0 && m->prof.ev.size() >= 2) {
     double ovh = 0.0;
     const int reps = 32;
     for (int i = 0; i < reps; ++i) {
-      HIPCHK(hipEventRecord(g_prof.ev[0], g_prof.stream));
-      HIPCHK(hipEventRecord(g_prof.ev[1], g_prof.stream));
-      HIPCHK(hipEventSynchronize(g_prof.ev[1]));
+      HIPCHK(hipEventRecord(m->prof.ev[0], m->prof.stream));
+      HIPCHK(hipEventRecord(m->prof.ev[1], m->prof.stream));
+      HIPCHK(hipEventSynchronize(m->prof.ev[1]));
       float ms = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[0], g_prof.ev[1]));
+      HIPCHK(hipEventElapsedTime(&ms, m->prof.ev[0], m->prof.ev[1]));
       ovh += ms;
     }
-    tot -= ovh / reps * g_prof.n;
+    tot -= ovh / reps * m->prof.n;
     if (tot < 0.0) tot = 0.0;
   }
   if (total_ms) *total_ms = tot;
-  if (launches) *launches = g_prof.n;
-  if (flops) *flops = g_prof.flops;
-  if (variant) *variant = g_prof.variant;
-  g_prof.site = -1;
+  if (launches) *launches = m->prof.n;
+  if (flops) *flops = m->prof.flops;
+  if (variant) *variant = m->prof.variant;
+  m->prof.site = -1;
   return JAT_OK;
 }
 extern "C" int jat_k_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream) {

@@ -54,8 +54,29 @@ struct FoldTable {
   ~FoldTable() { for (void* p : allocs) (void)hipFree(p); }
 };
 
+// Behaviour switches of one model handle: defaults from the JAT_* environment variables, read ONCE in jat_model_create (nothing on the
+// per-call enqueue path touches the environment), changed per handle with jat_model_set_switch.
+struct jat_switches {
+  int fuse_qkv_attn = 1;   // JAT_FUSE_QKV_ATTN: 0 separate QKV GEMM + attention, 1 fused when B * Hkv blocks fill the chip, 2 always (128 tokens)
+  int qkv_split = 1;       // JAT_QKV_SPLIT:     K-slices for the QKV GEMM of small buckets
+  int fuse_finish = 1;     // JAT_FUSE_FINISH:   split-K finishing pass fused with the norm that follows it
+  int fold_norm = 1;       // JAT_FOLD_NORM:     sampler norm folding (0 off, 1 buckets above kSplitMaxRows, 2 every bucket)
+  int split_patch = 1;     // JAT_SPLIT_PATCH:   CFG sampler: condition half of the first patch-embed Linear computed once per run
+  int gemm_dbg = 0;        // JAT_GEMM_DBG:      timing aids of gemm.hip (wrong results); 0 in production
+  int fold_cap_mb = 0;     // JAT_FOLD_CAP_MB:   upper bound on the folded-weight table (0 = none); beyond it the sampler keeps the norm kernels
+};
+// measurement aid (bench.py roofline leg): HIP-event brackets around the launches of one GEMM call site of THIS model
+struct GemmProf {
+  int site = -1, n = 0, variant = -1;
+  double flops = 0.0;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> ev;
+};
+
 struct jat_model {
   jat_config cfg;
+  jat_switches sw;
+  mutable GemmProf prof;
   int D, depth, Hq, Hkv, kvD, mlp, bott, Cin, Cc, P, Kp, Fout;
   bool loaded = false;
   char* blob = nullptr;  // one device allocation holding every packed tensor

@@ -79,22 +79,31 @@ def exchange_sum_(buf, group=None, async_op=False):
     links of every GPU busy with one direct transfer per peer (2 * 7/8 * n bytes per GPU in total, ~1/7 of it per link),
     where a ring all-reduce is bound by ONE link per direction (~5 ms vs ~35 ms for the 3.06 GB of fp32
     gradients).  Both collectives are in place (shard r of the output aliases the input, the NCCL/RCCL in-place form).
-    Falls back to one all_reduce when the length is not divisible by the world size.  Returns the list of work handles
-    (async_op=True) to wait on, in order.  UNMEASURED on hardware: no multi-GPU node was available to the build."""
+    Falls back to one all_reduce when the length is not divisible by the world size, and for slices below
+    `JAT_EXCHANGE_MIN_BYTES` (default 1 MiB: two collectives' launch latency outweighs the link argument there);
+    JAT_EXCHANGE_ALLREDUCE=1 forces plain all_reduce everywhere (A/B on hardware).  Returns the list of work handles
+    (async_op=True) to wait on, in order.  UNMEASURED on hardware: no multi-GPU node was available to the build — the
+    5 ms / 35 ms figures are a link-count model, not a measurement."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return []
     n = buf.numel()
     if buf.dim() != 1 or not buf.is_contiguous():
         raise ValueError("exchange_sum_ needs a contiguous 1-D tensor")
-    if n % world != 0:
+    import os
+    small = n * buf.element_size() < int(os.environ.get("JAT_EXCHANGE_MIN_BYTES", 1 << 20))
+    if n % world != 0 or small or os.environ.get("JAT_EXCHANGE_ALLREDUCE") == "1":
         w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return [w] if async_op else []
     rank = dist.get_rank(group)
     shard = n // world
     mine = buf[rank * shard:(rank + 1) * shard]
     w1 = dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-    if async_op and dist.get_backend(group) != "nccl":
-        w1.wait()    # RCCL orders the two collectives on the group's stream; gloo's async ops are unordered threads
+    if async_op:
+        # The all-gather reads the shard the reduce-scatter writes: order them EXPLICITLY on every backend instead of relying on
+        # the backend's own queueing.  With RCCL `wait()` makes the CURRENT stream (the caller's communication stream, see
+        # Trainer._on_grads_ready) wait for the collective's completion event — the host does not block; with gloo it joins the
+        # worker thread.  One code path: the branch an 8-GPU run takes is the branch the world_size-2 gloo test takes.
+        w1.wait()
     w2 = dist.all_gather_into_tensor(buf, mine, group=group, async_op=async_op)
     return [w1, w2] if async_op else []

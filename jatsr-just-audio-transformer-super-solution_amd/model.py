@@ -88,6 +88,11 @@ class _Handle:
             refs[i] = L.JatTensorRef(k.encode(), v.data_ptr(), v.numel())
         L.check(L.lib().jat_model_load_weights(self.ptr, refs, len(named), L.stream_ptr()))
 
+    def set_switch(self, name: str, value: int):
+        """Per-handle behaviour switch (jat_model_set_switch): the JAT_* environment variables only set the defaults, once, when the
+        handle is created.  Applies to forwards enqueued and samplers created afterwards."""
+        L.check(L.lib().jat_model_set_switch(self.ptr, name.encode(), int(value)))
+
     def workspace(self, B, T, device):
         need = C.c_size_t()
         L.check(L.lib().jat_model_workspace_bytes(self.ptr, B, T, C.byref(need)))

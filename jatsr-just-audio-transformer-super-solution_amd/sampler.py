@@ -138,6 +138,22 @@ def channel_affine(x, mean, std, inverse=False):
     return out
 
 
+def chunk_groups(lens, pad_short_chunks=True):
+    """Which chunks share a sampler launch: {bucket length T: [chunk indices]}.  One bucket per chunk length ... except that
+    SHORTER chunks ride along with the longest ones, zero-padded, their padded keys masked in attention and their padded frames
+    read as zeros (`Sampler.run(lengths=...)`): one launch for the whole file instead of a second, latency-bound one for a few
+    hundred frames.  A bucket of exactly 128 tokens runs the fused QKV+attention kernel, which has no key mask
+    (jat_sampler_set_lengths refuses it): there every length keeps its own bucket.  The ONE place that knows this rule
+    (sample_long, bench.py --mode long and dist.sample_long_sharded all come here)."""
+    Tmax = max(lens)
+    if pad_short_chunks and len(set(lens)) > 1 and (Tmax + 3) // 4 != 128:
+        return {Tmax: list(range(len(lens)))}
+    groups = {}
+    for i, n in enumerate(lens):
+        groups.setdefault(n, []).append(i)
+    return groups
+
+
 @torch.no_grad()
 def sample_long(model, lr_latent, hr_mean, hr_std, lr_mean, lr_std, num_steps=50, cfg_scale=1.0,
                 chunk_frames=1378, overlap_frames=172, noise=None, pad_short_chunks=True):
@@ -153,16 +169,7 @@ def sample_long(model, lr_latent, hr_mean, hr_std, lr_mean, lr_std, num_steps=50
     lr = lr_latent.unsqueeze(0)
     lens = [b - a for a, b in plan]
     outs = [None] * len(plan)
-    # One bucket per chunk length ... except that a SHORTER last chunk rides along with the full-length ones, zero-padded,
-    # its padded keys masked in attention and its padded frames read as zeros (`Sampler.run(lengths=...)`): one launch for
-    # the whole file instead of a second, latency-bound one for a few hundred frames.  A bucket of exactly 128 tokens
-    # runs the fused QKV+attention kernel, which has no key mask: there the short chunk keeps its own bucket.
-    Tmax = max(lens)
-    merge = pad_short_chunks and len(set(lens)) > 1 and (Tmax + 3) // 4 != 128
-    groups = {Tmax: list(range(len(plan)))} if merge else {}
-    if not merge:
-        for i, n in enumerate(lens):
-            groups.setdefault(n, []).append(i)
+    groups = chunk_groups(lens, pad_short_chunks)
     for length, idxs in groups.items():
         rows, noise_rows = [], []
         for i in idxs:

@@ -380,6 +380,9 @@ def main(which):
     if "v3mod2" in which:   # full-size model: ~15 GB of host memory, a few minutes; not part of the default set
         big_case("v3mod2_T128", "v3mod2", 2, 128, [0.2, 0.9], [False, True])
         big_case("v3mod2_T70_ragged", "v3mod2", 2, 70, [0.35, 0.8], [False, False], salt=1)
+    if "v3mod2ln" in which:  # BASELINE configs[3]'s own combination at full size: JaT_AudioSR_V2 (LayerNorm, depth 28, 766 M parameters)
+        # + MSE + latent perceptual loss (conditioned variant, fw = 0: comparable with reference autograd directly); ~20 GB, minutes
+        mod2_step_case("v3mod2_mod2fw0_T128", "v3mod2", 2, 128, [0.2, 0.9], salt=1, strides=(211, 97), fw=0.0)
     if allc or "charbonnier" in which:    # the V3M2-MOD1 trainer's reconstruction loss (train_ddp_v3m2mod1.py:72-101)
         charbonnier_case("T24", 2, 32, 24)
         charbonnier_case("T1378", 1, 8, 1378, salt=1)

@@ -32,3 +32,13 @@ def test_bench_starts_its_own_ranks_world2(scaling):
 def test_bench_dry_run_single_rank():
     r = _run(["--gpus", "1"])
     assert r["n_gpus"] == 1 and r["ranks_seen"] == 1
+
+
+@pytest.mark.parametrize("mode", ["train", "long"])
+def test_bench_launcher_other_modes_world2(mode):
+    """`--mode train` (configs[3]: the gradient exchange of jatsr_amd.dist.exchange_sum_, slice by slice, summed right on both
+    ranks) and `--mode long` (configs[4]: the chunk plan sharded round-robin, one object gather per file) through the same
+    self-launch + 127.0.0.1 rendezvous + barrier / max-over-ranks contract, world_size 2 on gloo."""
+    r = _run(["--gpus", "2", "--mode", mode])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["dry_run"] is True and r["config"]["mode"] == mode
+    assert r["steps"] == 3 and r["value"] > 0 and ("training" in r["metric"] if mode == "train" else "long-sequence" in r["metric"])

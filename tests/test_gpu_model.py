@@ -62,6 +62,35 @@ def test_forward_vs_reference_golden(name):
     assert abs(np.linalg.norm(o.astype(np.float64)) / float(z["out_l2"]) - 1) < 1e-2
 
 
+def test_forward_at_the_benchmarked_batch_vs_reference_golden():
+    """BASELINE configs[1] at its full size: the eval forward at B = 28, T = 512 (M = 3584 rows: other tile variants than any
+    small test — un-fused QKV GEMM + attn_group_kernel, per-sample adaLN modulation, 57 norm kernels).  Rows 0-1 are the two
+    samples of the `fwd_v3mod2_T512` reference golden (JaT_AudioSR_V3.forward in fp64, jat_audiosr_v3.py:422-471), rows 2-27 other
+    data with their own t: rows 0-1 must meet the golden's gate, agree with the B = 2 forward to rounding, and must not change
+    by a single bit when the OTHER 26 rows are permuted (batch-row independence of every kernel at this shape)."""
+    z, meta = load_golden("fwd_v3mod2_T512")
+    cfg, x_t, t, x_c = fwd_inputs(meta)
+    assert x_t.shape[0] == 2
+    m = build(meta["cfg"], meta["norm"], meta["salt"])
+    B, C, T = 28, x_t.shape[1], x_t.shape[2]
+    xo, co = recipe.make_latents(B - 2, C, T, salt=31)
+    to = np.linspace(0.03, 0.97, B - 2).astype(np.float32)
+    X, Cn, Tv = np.concatenate([x_t, xo]), np.concatenate([x_c, co]), np.concatenate([t, to])
+    out = m(cuda(X), cuda(Tv), cuda(Cn))
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all()
+    r = rel_l2(sub(o[:2], *meta["s_out"]), z["out64"])
+    ma = float(np.abs(sub(o[:2], *meta["s_out"]) - z["out64"]).max())
+    print(f"B=28 forward, rows 0-1 vs reference golden: rel-L2 {r:.3e} max-abs {ma:.3e}")
+    assert r < FWD_TOL and ma < FWD_MAXABS
+    small = m(cuda(x_t), cuda(t), cuda(x_c)).cpu().numpy()
+    assert rel_l2(o[:2], small) < 1e-2                     # other tiles, other bf16 rounding points; the same math
+    perm = np.concatenate([[0, 1], 2 + np.random.RandomState(0).permutation(B - 2)])
+    out_p = m(cuda(X[perm]), cuda(Tv[perm]), cuda(Cn[perm]))
+    assert torch.equal(out_p[:2], out[:2])
+    assert torch.equal(out_p[2:], out[torch.from_numpy(perm[2:]).cuda()])
+
+
 def test_forward_vs_oracle_micro_batch_rows_independent():
     """Same sample at different batch positions / with different neighbours gives the same result."""
     cfg = recipe.CONFIGS["micro"]
@@ -82,12 +111,13 @@ def test_fused_qkv_attention_is_bit_identical_to_separate_kernels(monkeypatch):
     z, meta = load_golden("fwd_v3mod2_T512")
     cfg, x_t, t, x_c = fwd_inputs(meta)
     m = build(meta["cfg"], meta["norm"], meta["salt"])
-    monkeypatch.setenv("JAT_FUSE_QKV_ATTN", "2")    # 2 = force (the default only fuses when B*Hkv fills the GPU)
+    h = m._get_handle()                             # switches are per handle (the JAT_* variables only set its defaults at creation)
+    h.set_switch("fuse_qkv_attn", 2)                # 2 = force (the default only fuses when B*Hkv fills the GPU)
     fused = m(cuda(x_t), cuda(t), cuda(x_c))
-    monkeypatch.setenv("JAT_FUSE_QKV_ATTN", "0")
-    monkeypatch.setenv("JAT_QKV_SPLIT", "0")        # the un-split QKV GEMM (a batch this small would split K: other summation order)
+    h.set_switch("fuse_qkv_attn", 0)
+    h.set_switch("qkv_split", 0)                    # the un-split QKV GEMM (a batch this small would split K: other summation order)
     separate = m(cuda(x_t), cuda(t), cuda(x_c))
-    monkeypatch.delenv("JAT_QKV_SPLIT")
+    h.set_switch("qkv_split", 1)
     split = m(cuda(x_t), cuda(t), cuda(x_c))         # the small-batch default: K-slices + splitk_qkv_finish_kernel
     assert rel_l2(split.cpu().numpy(), separate.cpu().numpy()) < 2e-3
     assert rel_l2(sub(split.cpu().numpy(), *meta["s_out"]), z["out64"]) < FWD_TOL
@@ -111,7 +141,7 @@ def test_split_k_finish_fused_with_the_following_norm(monkeypatch):
     cfg, x_t, t, x_c = fwd_inputs(meta)
     m = build(meta["cfg"], meta["norm"], meta["salt"])
     fused = m(cuda(x_t), cuda(t), cuda(x_c)).cpu().numpy()
-    monkeypatch.setenv("JAT_FUSE_FINISH", "0")
+    m._get_handle().set_switch("fuse_finish", 0)
     separate = m(cuda(x_t), cuda(t), cuda(x_c)).cpu().numpy()
     assert rel_l2(fused, separate) < 3e-3
     assert rel_l2(sub(fused, *meta["s_out"]), z["out64"]) < FWD_TOL

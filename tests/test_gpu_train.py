@@ -169,6 +169,43 @@ def test_v3mod2_B28_step_is_deterministic_and_finite():
     assert bool(torch.isfinite(after).all()) and not torch.equal(after, alone)
 
 
+def test_v3mod2_configs3_combination_at_full_size_is_deterministic_and_finite():
+    """BASELINE configs[3] in its own combination AND size on one GPU: JaT_AudioSR_V2 (LayerNorm without affine, depth 28) +
+    MSE + 0.3 x latent perceptual loss against the clean LR latent + condition noise, B = 28 per rank, T = 1378 (the trainer's crop,
+    N = 345 tokens: ragged tiles, the factored 26 x 53 DFT), Dropout 0.1 / DropPath 0..0.05 — in whatever operand dtype the
+    loaded library has (tests/test_gpu_fp16.py re-runs this under libjat_hip_fp16.so = train_ddp_v3mod2.py:706,745,854-896).
+    Same seed twice: bit-identical gradients and loss terms; everything finite; the latent term is live; one optimiser step
+    moves the weights."""
+    L.require_gpu()
+    cfg = recipe.CONFIGS["v3mod2"]
+    B, T, C = 28, 1378, cfg["input_channels"]
+    m = JaT_AudioSR_V2(**cfg, dropout=0.1, drop_path_rate=0.05)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg, "ln", 5).items()}, strict=False)
+    m = m.to("cuda")
+    tr = Trainer(m, batch_size=B, frames=T, use_grad_scaler=False, condition_noise_ratio=0.05, cfg_dropout_prob=0.0,
+                 latent_loss_weight=0.3, seed=11)
+    if FP16:
+        tr.scaler.scale = FP16_TEST_SCALE
+    hr = cuda(recipe.gaussian("train_hr", (B, C, T), 305))
+    lr = cuda(recipe.gaussian("train_lr", (B, C, T), 306))
+    noise = cuda(recipe.gaussian("train_noise", (B, C, T), 307))
+    cn = cuda(recipe.gaussian("train_cnoise", (B, C, T), 308))
+    t = cuda(np.linspace(0.03, 0.97, B).astype(np.float32))
+    z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cond_noise=cn, cfg_mask=torch.zeros(B, dtype=torch.bool), t=t)
+    tr.forward_backward(z_t, t2, cond, hr, cond_clean=lr, mask_seed=1234)
+    g1, terms1 = tr.grads.clone(), tr.loss_terms()
+    pred = tr.forward_backward(z_t, t2, cond, hr, cond_clean=lr, mask_seed=1234, want_pred=True)
+    assert torch.equal(tr.grads, g1) and tr.loss_terms() == terms1
+    assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(pred).all()) and all(math.isfinite(v) for v in terms1.values())
+    assert terms1["latent"] > 0 and terms1["mse"] > 0
+    assert abs(terms1["total"] - (terms1["mse"] + 0.3 * terms1["latent"])) <= 1e-4 * terms1["total"]   # train_ddp_v3mod2.py:889-896
+    tr.forward_backward(z_t, t2, cond, hr, cond_clean=lr, mask_seed=1235)
+    assert not torch.equal(tr.grads, g1)                       # another mask seed: another step
+    before = tr.params.clone()
+    loss, gnorm = tr.optimizer_step(lr=5e-5)
+    assert math.isfinite(loss) and math.isfinite(gnorm) and gnorm > 0 and not torch.equal(tr.params, before)
+
+
 def _check_step_vs_golden(name, with_adamw):
     z, meta = load_golden(name)
     m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
@@ -437,7 +474,7 @@ def test_v3mod2_step_vs_reference_golden(name):
     assert np.isfinite(st["loss"]) and np.isfinite(st["grad_norm"]) and tr.loss_terms()["latent"] > 0
 
 
-@pytest.mark.parametrize("name", ["train_micro_mod2fw0_T24", "train_tiny_mod2fw0_T128"])
+@pytest.mark.parametrize("name", ["train_micro_mod2fw0_T24", "train_tiny_mod2fw0_T128", "train_v3mod2_mod2fw0_T128"])
 def test_v3mod2_step_gradients_vs_reference_autograd_conditioned(name):
     """End-to-end v3mod2 gradients against the REFERENCE's own autograd (the `g_*` values gen_golden_train.py stored),
     on a well-conditioned variant of the loss: freq_weight = 0 removes the log-magnitude term whose d/d pred is

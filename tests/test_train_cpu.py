@@ -190,10 +190,10 @@ def test_gradient_allreduce_world2_gloo():
 def _exchange_worker(rank, world, port, out):
     import torch.distributed as dist
     from jatsr_amd.dist import exchange_sum_
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), JAT_EXCHANGE_MIN_BYTES="1024")   # small slices allowed here
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {}
-    for n, mode in ((4096, "sync"), (4096 + 64, "async"), (1001, "fallback")):   # 1001 % 2 != 0: one all_reduce instead
+    for n, mode in ((4096, "sync"), (4096 + 64, "async"), (1001, "fallback"), (64, "small")):   # 1001 % 2 != 0 / 256 B: all_reduce
         g = torch.Generator().manual_seed(100 + rank)
         buf = torch.randn(n, generator=g)
         ref = buf.clone()
