@@ -1628,7 +1628,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) gemm_persist_kernel(const Gem
 // before anyone reads them.  After the K loop the groups exchange halves of their partial accumulators through LDS (group 0
 // keeps row tiles 0-3 of its wave tile, group 1 row tiles 4-6; fp32 a + b in either order is the same number), and all 8 waves
 // run the split-residual epilogue of the one-tile kernels on their half.
-template <int EPI>
+template <int EPI, int LONGK>   // LONGK: a name tag only (K >= 4096: the MLP fc2; else out_proj / patch embed) so that the two call sites
+                                // of the sampler show as separate rows of a kernel trace
 __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   constexpr int TM = 7, TN = 5, BM = 224, BN = 160, NW = 8;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -1771,26 +1772,31 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   for (int j = 0; j < TN; ++j) bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
   auto up = [](unsigned u, float& a, float& b) { a = jat_lo2f(u); b = jat_hi2f(u); };
   auto half_epilogue = [&](auto i0c, auto ntc) __attribute__((always_inline)) {
-    constexpr int I0 = decltype(i0c)::value, NT = decltype(ntc)::value;
+    constexpr int I0 = decltype(i0c)::value, NT = decltype(ntc)::value, NG = (NT + 1) / 2;
     const int mw0 = m0 + wm * TM * 16 + I0 * 16;
-#pragma unroll
-    for (int ig = 0; ig < (NT + 1) / 2; ++ig) {
+    // ONE register set for the residual planes and the gate: chunk t of group ig+1 is requested right after chunk t of group ig has
+    // been consumed and BEFORE that chunk's stores are issued — a load issued behind a store would wait for the store to be
+    // acknowledged (vmcnt counts loads and stores in issue order), which used to expose the store latency once per group
+    [[maybe_unused]] uint4 hi[NCH8], lo[NCH8];
+    [[maybe_unused]] float4 g0[NCH8], g1[NCH8];
+    auto load_chunk = [&](int ig, int t) __attribute__((always_inline)) {
       const int grows = (2 * ig + 1 < NT) ? 32 : 16;
-      [[maybe_unused]] uint4 hi[NCH8], lo[NCH8];
-      [[maybe_unused]] float4 g0[NCH8], g1[NCH8];
-      if constexpr (EPI == EPI_RESID) {
+      const int c = lane + 64 * t, row = min(c / CPR8, grows - 1), cc = c - (c / CPR8) * CPR8;
+      const int m = mw0 + ig * 32 + row, n = nw0 + cc * 8;
+      const unsigned off = (unsigned)(m * (int)p.ldo + n) * 2u;   // uniform base + 32-bit lane offset (planes < 4 GB)
+      hi[t] = *(const uint4*)((const char*)p.fold_out + off);
+      lo[t] = *(const uint4*)((const char*)p.fold_lo + off);
+      const float* gp = p.gate + (int64_t)(m / p.ntok) * p.gate_bstride + n;
+      g0[t] = *(const float4*)gp;
+      g1[t] = *(const float4*)(gp + 4);
+    };
+    if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-        for (int t = 0; t < NCH8; ++t) {
-          const int c = lane + 64 * t, row = min(c / CPR8, grows - 1), cc = c - (c / CPR8) * CPR8;
-          const int m = mw0 + ig * 32 + row, n = nw0 + cc * 8;
-          const unsigned off = (unsigned)(m * (int)p.ldo + n) * 2u;   // uniform base + 32-bit lane offset (planes < 4 GB)
-          hi[t] = *(const uint4*)((const char*)p.fold_out + off);
-          lo[t] = *(const uint4*)((const char*)p.fold_lo + off);
-          const float* gp = p.gate + (int64_t)(m / p.ntok) * p.gate_bstride + n;
-          g0[t] = *(const float4*)gp;
-          g1[t] = *(const float4*)(gp + 4);
-        }
-      }
+      for (int t = 0; t < NCH8; ++t) load_chunk(0, t);
+    }
+#pragma unroll
+    for (int ig = 0; ig < NG; ++ig) {
+      const int grows = (2 * ig + 1 < NT) ? 32 : 16;
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -1818,6 +1824,7 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
             x[2 * e] = __builtin_fmaf(gg[2 * e], x[2 * e], h0 + l0);
             x[2 * e + 1] = __builtin_fmaf(gg[2 * e + 1], x[2 * e + 1], h1 + l1);
           }
+          if (ig + 1 < NG) load_chunk(ig + 1, t);        // this chunk's registers are free: the next group's chunk, before my stores
         }
         unsigned ho[4], lw2[4];
         float sq = 0.f;
@@ -1860,12 +1867,12 @@ static bool gemm_kpair_eligible(const GemmArgs& a, int epi) {
   return (epi == EPI_RESID || epi == EPI_F32) && a.fold_out && a.fold_lo && a.fold_part && a.M > 0 && a.M % 224 == 0 &&
          a.N % 160 == 0 && a.K % 64 == 0 && a.ksplit <= 1 && !a.rs_part;
 }
-template <int EPI>
+template <int EPI, int LONGK>
 static hipError_t launch_kpair(const GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 3 * (224 + 160) * 128;
   static_assert(LDS <= 160 * 1024, "three stages must fit the 160 KiB LDS");
   static bool attr_set = false;
-  auto kern = gemm_kpair_kernel<EPI>;
+  auto kern = gemm_kpair_kernel<EPI, LONGK>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
@@ -1983,7 +1990,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 28: return launch_epi<2, 2, 2, 4, 2, 1>(a, epi, s);
     case 31: return launch_epi<2, 4, 7, 5, 8, 1>(a, epi, s);
     case 39:
-      if (gemm_kpair_eligible(a, epi)) return epi == EPI_RESID ? launch_kpair<EPI_RESID>(a, s) : launch_kpair<EPI_F32>(a, s);
+      if (gemm_kpair_eligible(a, epi))
+        return epi != EPI_RESID ? launch_kpair<EPI_F32, 0>(a, s) : a.K >= 4096 ? launch_kpair<EPI_RESID, 1>(a, s) : launch_kpair<EPI_RESID, 0>(a, s);
       [[fallthrough]];
     case 32: return launch_epi<4, 2, 4, 5, 8, 1>(a, epi, s);
     case 33: return launch_epi<2, 4, 8, 4, 8, 1>(a, epi, s);

@@ -301,7 +301,7 @@ def loss_case(name, B, C, T, salt=0, lw=0.3, fw=0.5, mw=0.5, cw=0.1):
           f"ms={rec['ms']:.5f} cons={rec['consistency']:.5f}")
 
 
-def mod2_step_case(name, cfg_name, B, T, t_list, salt=0, strides=(7, 5), lw=0.3, fw=0.5, mw=0.5, cw=0.1):
+def mod2_step_case(name, cfg_name, B, T, t_list, salt=0, strides=(7, 5), lw=0.3, fw=0.5, mw=0.5, cw=0.1, stride1d=None):
     """One v3mod2 step end to end: JaT_AudioSR_V2 (LayerNorm) + MSE + latent perceptual loss with the clean LR latent
     (train_ddp_v3mod2.py:854-896), dropout = drop_path = 0, cond noise injected; gradients of every parameter (fp64
     model, the loss classes force fp32 internally exactly as in the trainer)."""
@@ -323,10 +323,10 @@ def mod2_step_case(name, cfg_name, B, T, t_list, salt=0, strides=(7, 5), lw=0.3,
     rec = {"loss64": np.float64(loss.item()), "mse": np.float64(mse.item()), "latent": np.float64(lat.item()),
            "pred_l2": np.float64(pred.detach().norm().item())}
     for k, p in m.named_parameters():
-        rec["g_" + k] = sub(p.grad.numpy(), strides)
+        rec["g_" + k] = sub(p.grad.numpy(), strides, stride1d)
         rec["gl2_" + k] = np.float64(p.grad.norm().item())
     rec["meta"] = json.dumps(dict(case=name, cfg=cfg_name, B=B, T=T, t=[float(v) for v in t], norm="ln", salt=salt,
-                                  lw=lw, fw=fw, mw=mw, cw=cw, full_limit=FULL_LIMIT, strides=strides,
+                                  lw=lw, fw=fw, mw=mw, cw=cw, full_limit=FULL_LIMIT, strides=strides, stride1d=stride1d,
                                   torch=torch.__version__, names=[k for k, _ in m.named_parameters()]))
     np.savez_compressed(os.path.join(GOLD, f"train_{name}.npz"), **rec)
     print(f"[golden] train_{name}: loss={rec['loss64']:.6f} (mse {rec['mse']:.6f} + {lw} * latent {rec['latent']:.5f})")
@@ -382,7 +382,7 @@ def main(which):
         big_case("v3mod2_T70_ragged", "v3mod2", 2, 70, [0.35, 0.8], [False, False], salt=1)
     if "v3mod2ln" in which:  # BASELINE configs[3]'s own combination at full size: JaT_AudioSR_V2 (LayerNorm, depth 28, 766 M parameters)
         # + MSE + latent perceptual loss (conditioned variant, fw = 0: comparable with reference autograd directly); ~20 GB, minutes
-        mod2_step_case("v3mod2_mod2fw0_T128", "v3mod2", 2, 128, [0.2, 0.9], salt=1, strides=(211, 97), fw=0.0)
+        mod2_step_case("v3mod2_mod2fw0_T128", "v3mod2", 2, 128, [0.2, 0.9], salt=1, strides=(211, 97), fw=0.0, stride1d=13)
     if allc or "charbonnier" in which:    # the V3M2-MOD1 trainer's reconstruction loss (train_ddp_v3m2mod1.py:72-101)
         charbonnier_case("T24", 2, 32, 24)
         charbonnier_case("T1378", 1, 8, 1378, salt=1)
