@@ -211,6 +211,12 @@ int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* C,
 int jat_k_gemm_fold(const uint16_t* A, const uint16_t* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K,
                     int32_t epilogue, const float* gate, int64_t gate_bstride, int32_t rows_per_batch, uint16_t* hi,
                     uint16_t* lo, float* part_out, const float* part_in, int32_t part_in_np, int32_t variant, void* stream);
+/* Split-K slices of the same product: parts[z][M][N] fp32 = A[:, z K/ksplit : (z+1) K/ksplit] W[:, same]^T, z < ksplit, no
+ * bias; summed in order by the caller / the finishing pass.  This is what the un-folded forward's fc2 and out_proj
+ * (jat_audiosr_v3.py:300,306) launch when their tiles would leave CUs idle; variant 39 = the 224 x 160 k-step-pair tile
+ * (M % 224 == 0, N % 160 == 0, K / ksplit a multiple of 64 and >= 192). */
+int jat_k_gemm_splitk(const uint16_t* A, const uint16_t* W, float* parts, int32_t M, int32_t N, int32_t K, int32_t ksplit,
+                      int32_t variant, void* stream);
 /* Fused QKV projection + RoPE + GQA attention for 128-token samples (the sampler's form of jat_audiosr_v3.py:154-181 when
  * B * Hkv blocks fill the chip): A [M, K] (M % 128 == 0), Wg = the group-major fused weight [Hkv][5*64 + 64 + 64][K] with q / k rows
  * pair-interleaved per head (as jat_model_load_weights packs it), out [M, Hkv*320] = attention output; bias / part_in as in

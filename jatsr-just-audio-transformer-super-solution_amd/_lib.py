@@ -57,6 +57,7 @@ SIGNATURES = {
     "jat_k_norm_modulate": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _I32, _I32, _I32, _VP]),
     "jat_k_gemm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _I64, _I32, _I32, _VP]),
     "jat_k_gemm_fold": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _I64, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
+    "jat_k_gemm_splitk": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "jat_k_gemm_wave_n": (C.c_int, [_I32]),
     "jat_k_qkv_attn": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "jat_k_weight_grad": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),

@@ -1628,8 +1628,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) gemm_persist_kernel(const Gem
 // before anyone reads them.  After the K loop the groups exchange halves of their partial accumulators through LDS (group 0
 // keeps row tiles 0-3 of its wave tile, group 1 row tiles 4-6; fp32 a + b in either order is the same number), and all 8 waves
 // run the split-residual epilogue of the one-tile kernels on their half.
-template <int EPI, int LONGK>   // LONGK: a name tag only (K >= 4096: the MLP fc2; else out_proj / patch embed) so that the two call sites
-                                // of the sampler show as separate rows of a kernel trace
+template <int EPI, int LONGK, bool PART = false>   // LONGK: a name tag only (K >= 4096: the MLP fc2; else out_proj / patch embed) so that
+                                                   // the two call sites of the sampler show as separate rows of a kernel trace
+// PART: a split-K slice (blockIdx.y) of an un-folded GEMM — the tile's fp32 sums go to slice z of the partial workspace, no bias, no
+// planes; the finishing pass (elementwise.hip: splitk_resid_*) sums the slices in fixed order.  This is how a half-size batch
+// (M = 3584: 128 tiles) still puts one fat tile on each of the 256 CUs.
 __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   constexpr int TM = 7, TN = 5, BM = 224, BN = 160, NW = 8;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -1660,6 +1663,7 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
     n0 = (in_g / gsz) * BN;
   }
   const int nk = p.K / 64;
+  const int64_t kz = PART ? (int64_t)blockIdx.y * p.K : 0;      // my slice's first column of A and W (p.K = the slice depth)
   // my DMA pieces: piece q = wave + 8 j covers image rows 8 q .. 8 q + 7 (A rows first, then W rows); whole tiles: no clamp
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
   const char* psrc[CP];
@@ -1668,8 +1672,8 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   for (int j = 0; j < CP; ++j) {
     const int q = wave + NW * j, r = q * 8;
     pdst[j] = r * 128;
-    psrc[j] = r < BM ? (const char*)(p.A + (int64_t)(m0 + r + srow) * p.lda) + schunk * 16
-                     : (const char*)(p.W + (int64_t)(n0 + r - BM + srow) * p.ldw) + schunk * 16;
+    psrc[j] = r < BM ? (const char*)(p.A + (int64_t)(m0 + r + srow) * p.lda + kz) + schunk * 16
+                     : (const char*)(p.W + (int64_t)(n0 + r - BM + srow) * p.ldw + kz) + schunk * 16;
   }
   auto dma_tile = [&](int kt) {
     char* st = smem + (kt % 3) * STAGE;
@@ -1769,8 +1773,9 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
   const int nw0 = n0 + wn * TN * 16;
   float4 bb[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) bb[j] = p.bias ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < TN; ++j) bb[j] = (!PART && p.bias) ? *(const float4*)(p.bias + nw0 + j * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
   auto up = [](unsigned u, float& a, float& b) { a = jat_lo2f(u); b = jat_hi2f(u); };
+  [[maybe_unused]] float* const pout = PART ? (float*)p.out + (int64_t)blockIdx.y * p.split_stride : nullptr;
   auto half_epilogue = [&](auto i0c, auto ntc) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0c)::value, NT = decltype(ntc)::value, NG = (NT + 1) / 2;
     const int mw0 = m0 + wm * TM * 16 + I0 * 16;
@@ -1813,6 +1818,14 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
         char* slot = wbuf + (row < 32 ? row : 0) * RS + cc * 32;
         const float4 a0 = *(const float4*)slot, a1 = *(const float4*)(slot + 16);
         float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        if constexpr (PART) {      // the slice's sums as they are: 32 B per lane, 320 B per row and wave
+          if (row < grows) {
+            float* o = pout + (int64_t)m * p.ldo + n;
+            *(float4*)o = a0;
+            *(float4*)(o + 4) = a1;
+          }
+          continue;
+        }
         if constexpr (EPI == EPI_RESID) {
           const unsigned hw[4] = {hi[t].x, hi[t].y, hi[t].z, hi[t].w}, lw[4] = {lo[t].x, lo[t].y, lo[t].z, lo[t].w};
           const float gg[8] = {g0[t].x, g0[t].y, g0[t].z, g0[t].w, g1[t].x, g1[t].y, g1[t].z, g1[t].w};
@@ -1845,7 +1858,7 @@ __global__ void __launch_bounds__(512, 1) gemm_kpair_kernel(const GemmArgs p) {
         if (row < 32) *(float*)slot = live ? sq : 0.f;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      {  // row partial sums over this wave's columns: two lanes per row, fixed order
+      if constexpr (!PART) {  // row partial sums over this wave's columns: two lanes per row, fixed order
         constexpr int HALF = CPR8 / 2;
         const int r = lane >> 1, h = lane & 1;
         float sq = 0.f;
@@ -1867,18 +1880,23 @@ static bool gemm_kpair_eligible(const GemmArgs& a, int epi) {
   return (epi == EPI_RESID || epi == EPI_F32) && a.fold_out && a.fold_lo && a.fold_part && a.M > 0 && a.M % 224 == 0 &&
          a.N % 160 == 0 && a.K % 64 == 0 && a.ksplit <= 1 && !a.rs_part;
 }
-template <int EPI, int LONGK>
+// split-K slices of an un-folded GEMM on the same tile (a.K = the slice depth, jat_gemm)
+static bool gemm_kpair_part_eligible(const GemmArgs& a, int epi) {
+  return epi == EPI_F32 && a.ksplit > 1 && !a.fold_out && !a.rs_part && !a.dual_rows && a.out && a.M > 0 && a.M % 224 == 0 &&
+         a.N % 160 == 0 && a.K % 64 == 0 && a.K >= 192;
+}
+template <int EPI, int LONGK, bool PART = false>
 static hipError_t launch_kpair(const GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 3 * (224 + 160) * 128;
   static_assert(LDS <= 160 * 1024, "three stages must fit the 160 KiB LDS");
   static bool attr_set = false;
-  auto kern = gemm_kpair_kernel<EPI, LONGK>;
+  auto kern = gemm_kpair_kernel<EPI, LONGK, PART>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.M / 224) * (a.N / 160)), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((a.M / 224) * (a.N / 160), PART ? a.ksplit : 1), dim3(512), LDS, s, a);
   return hipGetLastError();
 }
 
@@ -1990,6 +2008,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     case 28: return launch_epi<2, 2, 2, 4, 2, 1>(a, epi, s);
     case 31: return launch_epi<2, 4, 7, 5, 8, 1>(a, epi, s);
     case 39:
+      if (gemm_kpair_part_eligible(a, epi)) return launch_kpair<EPI_F32, 0, true>(a, s);
       if (gemm_kpair_eligible(a, epi))
         return epi != EPI_RESID ? launch_kpair<EPI_F32, 0>(a, s) : a.K >= 4096 ? launch_kpair<EPI_RESID, 1>(a, s) : launch_kpair<EPI_RESID, 0>(a, s);
       [[fallthrough]];

@@ -379,7 +379,7 @@ int jat_gemm(const jat_model* m, int site, const bf16_t* A, int64_t lda, const b
   GemmArgs a = extra;
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
   if (a.ksplit > 1) a.K = K / a.ksplit;   // per-slice depth; the kernel shifts A / W / out by blockIdx.y
-  int variant = m->variants[site] >= 0 ? m->variants[site] : pick_variant(M, N, a.ksplit > 1 ? a.ksplit : 1);
+  int variant = m->variants[site] >= 0 ? m->variants[site] : a.variant_hint > 0 ? a.variant_hint : pick_variant(M, N, a.ksplit > 1 ? a.ksplit : 1);
   if ((a.fold_out || a.rs_part) && !gemm_variant_coalesced(variant)) variant = 20;  // folding lives in the CE epilogues
   if (N % kTileN(variant) != 0) variant = 20;  // 128 x 128, always valid
   if (a.fold_out) { a.fold_np = N / gemm_variant_wave_n(variant); m->last_fold_np = a.fold_np; }
@@ -423,7 +423,8 @@ struct Fold {
 };
 
 // K-slices for a gated-residual GEMM [M, D] = A[M, K] W^T whose tiles do not fill the chip (small-M inference), 1 = none
-static int resid_split(const jat_model* m, const Workspace& w, int site, int M, int K, bool folding) {
+static int resid_split(const jat_model* m, const Workspace& w, int site, int M, int K, bool folding, int* variant = nullptr) {
+  if (variant) *variant = -1;
   if (!w.kpart || folding || K < 1024 || m->variants[site] >= 0) return 1;
   auto slices = [&](int v, int cap) {
     int bm, bn;
@@ -441,6 +442,17 @@ static int resid_split(const jat_model* m, const Workspace& w, int site, int M, 
   // a mid-size un-folded bucket (a T = 4096 file: M = 2760): the 64 x 128 tiles that fill the chip un-split are bound by the
   // per-CU L2->LDS rate (24 KB per K-tile and block, two blocks per CU); for the long-K fc2 two slices of 128 x 128 tiles
   // (the same 440 blocks, 2/3 of the bytes per flop) + the finishing pass are faster: 70 -> 45 us
+  // A half-size batch (configs[1]'s single forward, M = 3584): the 224 x 160 k-step-pair tile makes 128 tiles — two K slices
+  // put one on every CU (tile bytes per flop: 0.011 against 0.022 for the 64 x 160 tiles that fill the chip un-split); the
+  // finishing pass also applies the norm that follows, which saves the separate norm launch.  JAT_KPAIR_SPLIT=0: A/B
+  static const int kpair_split = getenv("JAT_KPAIR_SPLIT") ? atoi(getenv("JAT_KPAIR_SPLIT")) : 1;
+  if (kpair_split && variant && M % 224 == 0 && m->D % 160 == 0) {
+    const int tiles = (M / 224) * (m->D / 160);
+    int split = tiles <= 128 ? 256 / tiles : 1;
+    if (split > 2) split = 2;                      // the workspace of this bucket holds two slices (carve)
+    while (split > 1 && ((K / 64) % split != 0 || K / split < 512)) --split;
+    if (split > 1 && (K >= 4096 || kpair_split >= 2)) { *variant = 39; return split; }
+  }
   return K >= 4096 ? slices(20, 2) : 1;
 }
 
@@ -514,10 +526,11 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.gate = mod_l + 2 * D; e.gate_bstride = bstride; e.ntok = ntok;
     if (f) { e.fold_out = w.xn; e.fold_lo = w.xlo; e.fold_part = w.part; }
-    const int split = resid_split(m, w, G_OUT, M, D, f != nullptr);
+    int sv = -1;
+    const int split = resid_split(m, w, G_OUT, M, D, f != nullptr, &sv);
     if (split > 1) {
       GemmArgs p{};
-      p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D;
+      p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D; p.variant_hint = sv;
       JCHK(gemm(m, G_OUT, w.ao, D, L.wo, D, M, D, D, EPI_F32, p, s));
       if (can_fuse && !f) {   // slice sum + gate + residual + norm2 in one launch
         KCHK(launch_splitk_resid_norm(w.kpart, split, (int64_t)M * D, nullptr, mod_l + 2 * D, bstride, w.x, L.norm2, mod_l + 3 * D,
@@ -541,10 +554,11 @@ static int run_block(const jat_model* m, const Workspace& w, int l, int B, int n
     GemmArgs e{};
     e.out = w.x; e.ldo = D; e.bias = L.b2; e.gate = mod_l + 5 * D; e.gate_bstride = bstride; e.ntok = ntok;
     if (f) { e.fold_out = w.xn; e.fold_lo = w.xlo; e.fold_part = w.part; }   // feeds the next layer's norm1, or the final norm
-    const int split = resid_split(m, w, G_FC2, M, m->mlp, f != nullptr);
+    int sv = -1;
+    const int split = resid_split(m, w, G_FC2, M, m->mlp, f != nullptr, &sv);
     if (split > 1) {
       GemmArgs p{};
-      p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D;
+      p.out = w.kpart; p.ldo = D; p.ntok = ntok; p.ksplit = split; p.split_stride = (int64_t)M * D; p.variant_hint = sv;
       JCHK(gemm(m, G_FC2, w.hm, m->mlp, L.w2, m->mlp, M, D, m->mlp, EPI_F32, p, s));
       if (can_fuse && !f && next) {   // + the norm that reads this block's output
         KCHK(launch_splitk_resid_norm(w.kpart, split, (int64_t)M * D, L.b2, mod_l + 5 * D, bstride, w.x, next->w, next->shift,
@@ -1054,6 +1068,19 @@ extern "C" int jat_k_gemm(const uint16_t* A, const uint16_t* W, const float* bia
   if (const char* d = getenv("JAT_GEMM_DBG")) a.dbg = atoi(d);
   if (const char* d = getenv("JAT_GEMM_TIMELINE")) a.dbg_out = (unsigned long long*)strtoull(d, nullptr, 0);  // tools/gemm_timeline.py
   KCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
+  return JAT_OK;
+}
+// split-K slices of C = A W^T: parts[z][M][N] fp32 = the sum over K columns [z K/ksplit, (z+1) K/ksplit); the caller (or the
+// finishing passes of elementwise.hip) adds the slices in order.  The un-folded forward's fc2 / out_proj use it when their
+// tiles leave CUs idle (resid_split); variant 39 = the 224 x 160 k-step-pair tile (M % 224 == 0, N % 160 == 0).
+extern "C" int jat_k_gemm_splitk(const uint16_t* A, const uint16_t* W, float* parts, int32_t M, int32_t N, int32_t K,
+                                 int32_t ksplit, int32_t variant, void* stream) {
+  if (!A || !W || !parts || M <= 0 || N <= 0 || ksplit < 2 || K % (64 * ksplit) != 0) return fail(JAT_E_INVALID, "bad argument");
+  if (!gemm_variant_exists(variant)) return fail(JAT_E_INVALID, "unknown variant");
+  GemmArgs a{};
+  a.A = A; a.W = W; a.lda = K; a.ldw = K; a.M = M; a.N = N; a.K = K / ksplit;
+  a.out = parts; a.ldo = N; a.ntok = 1; a.ksplit = ksplit; a.split_stride = (int64_t)M * N;
+  KCHK(launch_gemm(a, EPI_F32, variant, (hipStream_t)stream));
   return JAT_OK;
 }
 extern "C" int jat_k_gemm_wave_n(int32_t variant) { return gemm_variant_exists(variant) ? gemm_variant_wave_n(variant) : 0; }

@@ -65,6 +65,7 @@ struct GemmArgs {
   // (fp32 elements); the caller sums the partials in fixed order (launch_sum_partials).  0 / 1: off.
   int ksplit;
   int64_t split_stride;
+  int variant_hint;   // host side only (jat_gemm): > 0 = the tile variant the caller's split plan was made for
 };
 
 // variant: index into the tile/pipeline table of gemm.hip (gemm_variant_tile gives its BM x BN)

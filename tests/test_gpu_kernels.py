@@ -209,6 +209,27 @@ def test_gemm_kpair_kernel(M, N, K, ntok, epi):
     assert rel(part.double().sum(1), (ref * ref).sum(1)) < 1e-5
 
 
+@pytest.mark.parametrize("variant,M,N,K,ksplit", [(39, 224, 160, 384, 2), (39, 448, 320, 1280, 2), (39, 3584, 1280, 5120, 2),
+                                                  (39, 224, 1280, 2560, 4), (20, 200, 256, 512, 2), (20, 3584, 1280, 5120, 2)])
+def test_gemm_splitk_slices(variant, M, N, K, ksplit):
+    """Split-K slices (jat_k_gemm_splitk): slice z = the product over its K columns alone, for the plain 128 x 128 tile and for
+    the 224 x 160 k-step-pair tile the half-size forward (BASELINE configs[1], M = 3584) cuts fc2 with; every slice against
+    fp64, the rest of the workspace untouched, deterministic."""
+    A, Af = bf16_bits(gen((M, K), 260))
+    W, Wf = bf16_bits(gen((N, K), 261, 1.0 / np.sqrt(K)))
+    res = []
+    for _ in range(2):
+        parts = torch.full((ksplit + 1, M, N), float("nan"), device=A.device)
+        L.check(L.lib().jat_k_gemm_splitk(L.ptr(A), L.ptr(W), L.ptr(parts), M, N, K, ksplit, variant, L.stream_ptr()))
+        torch.cuda.synchronize()
+        res.append(parts)
+    assert torch.equal(res[0][:ksplit], res[1][:ksplit]) and torch.isnan(res[0][ksplit]).all()
+    ks = K // ksplit
+    for z in range(ksplit):
+        ref = Af[:, z * ks:(z + 1) * ks].double() @ Wf[:, z * ks:(z + 1) * ks].double().T
+        assert (res[0][z].double() - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("variant", [31, 36])
 @pytest.mark.parametrize("np_", [4, 8, 16])
 @pytest.mark.parametrize("epi", [1, 2])
