@@ -368,16 +368,23 @@ __global__ void __launch_bounds__(NWV * 64) attn_group_kernel(const AttnArgs p) 
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.N <= 0 || a.B <= 0 || a.Hq % a.Hkv != 0 || a.npad % 64 != 0 || a.npad < a.N) return hipErrorInvalidValue;
-  constexpr int QT = 2;
-  dim3 grid((a.N + 64 * QT - 1) / (64 * QT), a.Hq, a.B);
   static const int kvb_env = getenv("JAT_ATTN_KVB") ? atoi(getenv("JAT_ATTN_KVB")) : 64;
   static const int group_env = getenv("JAT_ATTN_GROUP") ? atoi(getenv("JAT_ATTN_GROUP")) : 1;
+  static const int qt_env = getenv("JAT_ATTN_QT") ? atoi(getenv("JAT_ATTN_QT")) : 0;   // 0: by block count
+  // 32 queries per wave (QT = 2) halve the K/V traffic per query, but one chunk (B = 2 with CFG, N = 345) then makes 120 blocks
+  // for 256 CUs: below one block per CU take 16 queries per wave
+  const long blocks2 = (long)((a.N + 127) / 128) * a.Hq * a.B;
+  const int qt = qt_env ? qt_env : (blocks2 < 256 ? 1 : 2);
+  dim3 grid((a.N + 64 * qt - 1) / (64 * qt), a.Hq, a.B);
+  const bool kvb64 = kvb_env == 64 || a.N <= 64;
   if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse && !a.drop.thresh) {   // the sampler's shape: K/V staged once per KV head (lens honoured)
     hipLaunchKernelGGL((attn_group_kernel<1, 8>), dim3(a.Hkv, a.B), dim3(512), 0, s, a);
-  } else if (kvb_env == 64 || a.N <= 64) {
-    hipLaunchKernelGGL((attn_fwd_kernel<QT, 64>), grid, dim3(256), 0, s, a);
+  } else if (qt == 1) {
+    if (kvb64) hipLaunchKernelGGL((attn_fwd_kernel<1, 64>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<1, 128>), grid, dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((attn_fwd_kernel<QT, 128>), grid, dim3(256), 0, s, a);
+    if (kvb64) hipLaunchKernelGGL((attn_fwd_kernel<2, 64>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<2, 128>), grid, dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }

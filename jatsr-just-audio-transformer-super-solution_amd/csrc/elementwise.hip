@@ -110,6 +110,15 @@ __global__ void __launch_bounds__(256) norm_modulate_rows_kernel(const float* __
 #pragma unroll
       for (int c = 0; c < NCH; ++c) nxt[c] = *(const f32x4_e*)(x + (int64_t)next * D + c * 256 + lane * 4);
     }
+    // this row's modulation does not depend on its statistics: request it before the shuffle reduction, not after
+    const int b = row / ntok;
+    const float* sh = shift ? shift + (int64_t)b * mod_bstride + lane * 4 : nullptr;
+    const float* sc = scale ? scale + (int64_t)b * mod_bstride + lane * 4 : nullptr;
+    f32x4_e ma[NCH], ms[NCH];
+    if (sc) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) { ma[c] = *(const f32x4_e*)(sc + c * 256); ms[c] = *(const f32x4_e*)(sh + c * 256); }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -128,18 +137,11 @@ __global__ void __launch_bounds__(256) norm_modulate_rows_kernel(const float* __
         for (int e = 0; e < 4; ++e) var += (cur[c][e] - mu) * (cur[c][e] - mu);
       rstd = rsqrtf(wave_sum(var) / (float)D + 1e-6f);
     }
-    const int b = row / ntok;
-    const float* sh = shift ? shift + (int64_t)b * mod_bstride + lane * 4 : nullptr;
-    const float* sc = scale ? scale + (int64_t)b * mod_bstride + lane * 4 : nullptr;
     bf16_t* yr = y + (int64_t)row * D + lane * 4;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       f32x4_e t = (cur[c] - mu) * rstd * ww[c];
-      if (sc) {
-        const f32x4_e a = *(const f32x4_e*)(sc + c * 256);
-        const f32x4_e s = *(const f32x4_e*)(sh + c * 256);
-        t = t * (1.f + a) + s;
-      }
+      if (sc) t = t * (1.f + ma[c]) + ms[c];
       *(uint2*)(yr + c * 256) = pack4_e(t[0], t[1], t[2], t[3]);
     }
     if (next >= M) break;
@@ -271,20 +273,33 @@ __global__ void __launch_bounds__(256) linear_f32_kernel(const float* __restrict
   for (int c = 0; c < 8; ++c)
     if (c < nch) w[c] = *(const float4*)(W + (int64_t)n * K + c * 256 + lane * 4);
   const float bn = bias ? bias[n] : 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* xr = in + (int64_t)b * K + lane * 4;
-    float acc = 0.f;
+  // four batch rows at a time: their loads and shuffle reductions are independent chains that interleave (one row at a time
+  // left every step of a 28-row batch waiting on the previous row's six dependent shuffles: 46 us per call); each row's own
+  // summation order is unchanged
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c < nch) {
-        const float4 xv = *(const float4*)(xr + c * 256);
-        acc += xv.x * w[c].x + xv.y * w[c].y + xv.z * w[c].z + xv.w * w[c].w;
+    for (int r = 0; r < 4; ++r) {
+      const int b = min(b0 + r, B - 1);
+      const float* xr = in + (int64_t)b * K + lane * 4;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < nch) {
+          const float4 xv = *(const float4*)(xr + c * 256);
+          acc[r] += xv.x * w[c].x + xv.y * w[c].y + xv.z * w[c].z + xv.w * w[c].w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = wave_sum(acc[r]) + bn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + r;
+      float v = acc[r];
+      if (act_out == 1) v = silu_f(v);
+      if (lane == 0 && b < B) {
+        out[(int64_t)b * N + n] = v;
+        if (out_silu) out_silu[(int64_t)b * N + n] = f2bf_e(silu_f(v));
       }
-    acc = wave_sum(acc) + bn;
-    if (act_out == 1) acc = silu_f(acc);
-    if (lane == 0) {
-      out[(int64_t)b * N + n] = acc;
-      if (out_silu) out_silu[(int64_t)b * N + n] = f2bf_e(silu_f(acc));
     }
   }
 }
