@@ -103,6 +103,11 @@ int jat_time_embed(jat_model* m, const float* t, float* t_emb, int32_t B, void* 
 int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t steps, float cfg_scale,
                        jat_sampler** out);
 void jat_sampler_destroy(jat_sampler* s);
+/* What the sampler's captured graph runs: *folded != 0 = per-step folded weights (0 after the fallback to the
+ * norm kernels: not an RMSNorm model, over the "fold_cap_mb" switch, or the table did not fit the device), *fused_attn != 0 = the
+ * fused QKV + RoPE + attention kernel, *fold_bytes = size of the folded-weight table shared through the model.  Any pointer
+ * may be NULL. */
+int jat_sampler_info(const jat_sampler* sampler, int32_t* folded, int32_t* fused_attn, int64_t* fold_bytes);
 /* Rows of the bucket that are SHORTER than T (the last chunk of a file, infer_test_v3m2.py:353-361,370-398, batched with
  * the full-length chunks instead of sampled alone): frames[b] in (0, T] valid latent frames of row b; the caller zero-pads
  * lr_latent / z0 beyond them and ignores z_out there.  Attention masks the padded keys, every other operator is row-wise,

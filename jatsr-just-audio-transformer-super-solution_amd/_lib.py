@@ -50,6 +50,7 @@ SIGNATURES = {
     "jat_sampler_create": (C.c_int, [_VP, _I32, _I32, _I32, _F32, C.POINTER(_VP)]),
     "jat_sampler_destroy": (None, [_VP]),
     "jat_sampler_run": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP]),
+    "jat_sampler_info": (C.c_int, [_VP, _VP, _VP, _VP]),
     "jat_sampler_set_lengths": (C.c_int, [_VP, C.POINTER(_I32), _I32, _VP]),
     "jat_cfg_euler_step": (C.c_int, [_VP, _VP, _F32, _F32, _F32, _I32, _I32, _I32, _VP]),
     "jat_channel_affine": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),

@@ -994,6 +994,20 @@ extern "C" int jat_sampler_create(jat_model* m, int32_t B, int32_t T, int32_t st
   return JAT_OK;
 }
 
+// what this sampler's captured graph runs: folded != 0 = per-step folded weights (no norm kernels), fused_attn != 0 = the fused
+// QKV + RoPE + attention kernel, fold_bytes = size of the folded-weight table it shares through the model (0 when not folded)
+extern "C" int jat_sampler_info(const jat_sampler* sp, int32_t* folded, int32_t* fused_attn, int64_t* fold_bytes) {
+  if (!sp) return fail(JAT_E_INVALID, "null sampler");
+  if (folded) *folded = sp->folded ? 1 : 0;
+  if (fused_attn) *fused_attn = sp->fused_attn ? 1 : 0;
+  if (fold_bytes) {
+    const jat_model* m = sp->m;
+    const size_t Nq = (size_t)m->D + 2 * m->kvD;
+    *fold_bytes = sp->folded ? (int64_t)((size_t)sp->steps * m->depth * ((Nq + m->mlp) * m->D * 2 + (Nq + m->mlp) * 4) + (size_t)m->Fout * m->D * 2) : 0;
+  }
+  return JAT_OK;
+}
+
 extern "C" int jat_sampler_set_lengths(jat_sampler* sp, const int32_t* frames, int32_t n, void* stream) {
   if (!sp || !frames) return fail(JAT_E_INVALID, "null argument");
   if (n != sp->B) return fail(JAT_E_INVALID, "need one length per batch row (%d), got %d", sp->B, n);

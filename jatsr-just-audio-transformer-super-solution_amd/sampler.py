@@ -45,6 +45,13 @@ class Sampler:
         except Exception:
             pass
 
+    def info(self):
+        """{'folded': per-step folded weights in use, 'fused_attn': fused QKV+RoPE+attention kernel, 'fold_bytes': table size}
+        (`jat_sampler_info`): what the captured graph of this bucket runs."""
+        f, a, n = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        L.check(L.lib().jat_sampler_info(self.ptr, C.byref(f), C.byref(a), C.byref(n)))
+        return {"folded": bool(f.value), "fused_attn": bool(a.value), "fold_bytes": int(n.value)}
+
     def run(self, lr_latent, z0, use_graph=True, lengths=None):
         """lengths: optional valid frame count per batch row (rows shorter than the bucket's T, zero-padded by the caller:
         the last chunk of a file batched with the full-length ones).  Their valid frames equal a stand-alone run."""

@@ -291,6 +291,32 @@ def test_sampler_with_norm_folding_matches_golden(monkeypatch):
     assert rel_l2(sub(a.cpu().numpy(), *meta["s_out"]), z["z"]) < SAMPLER_TOL
 
 
+def test_sampler_over_the_fold_table_cap_falls_back_to_the_norm_kernels():
+    """The per-step folded weights cost HBM (0.5 GB per step for v3mod2).  A handle whose "fold_cap_mb" switch is below the
+    table's size must build the SAME sampler with the norm kernels instead — within the parity gate of the reference golden,
+    deterministic — and leave nothing half-built behind: lifting the cap on the same handle folds again."""
+    z, meta = load_golden("sampler_tiny_cfg3")
+    cfg, lr, z0 = sampler_inputs(meta)
+    m = JaT_AudioSR_V3(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict(cfg).items()}, strict=False)
+    m = m.to("cuda").eval()
+    h = m._get_handle()
+    h.set_switch("fold_norm", 2)                   # fold at this small M too
+    h.set_switch("fold_cap_mb", 1)                 # the tiny model's table is ~100x that
+    B, T = lr.shape[0], lr.shape[2]
+    capped = jatsr_amd.Sampler(m, B, T, meta["steps"], meta["cfg_scale"])
+    assert capped.info() == {"folded": False, "fused_attn": capped.info()["fused_attn"], "fold_bytes": 0}
+    a = capped.run(cuda(lr), cuda(z0))
+    assert torch.equal(a, capped.run(cuda(lr), cuda(z0)))
+    assert rel_l2(sub(a.cpu().numpy(), *meta["s_out"]), z["z"]) < SAMPLER_TOL
+    h.set_switch("fold_cap_mb", 0)
+    folded = jatsr_amd.Sampler(m, B, T, meta["steps"], meta["cfg_scale"])
+    assert folded.info()["folded"] and folded.info()["fold_bytes"] > (1 << 20)
+    b = folded.run(cuda(lr), cuda(z0))
+    assert rel_l2(sub(b.cpu().numpy(), *meta["s_out"]), z["z"]) < SAMPLER_TOL
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < SAMPLER_TOL
+
+
 def test_sampler_at_benchmarked_shape_vs_reference_golden():
     """BASELINE configs[2] dims: v3mod2 (D = 1280, depth 28, 20Q/4KV), T = 512, CFG = 3.0, against the reference's own
     `flow_matching_sample` (4 Euler steps, fixture generated by oracle/gen_golden.py on the reference classes).

@@ -10,6 +10,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=28)
 ap.add_argument("--T", type=int, default=512)
 ap.add_argument("--runs", type=int, default=8)
+ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--tag", default="")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -20,8 +22,9 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=Fa
 model = model.to(dev).eval()
 lr = torch.from_numpy(recipe.gaussian("lr_latent", (a.B, 1024, a.T), 1234)).to(dev)
 z0 = torch.from_numpy(recipe.gaussian("z0", (a.B, 1024, a.T), 1235)).to(dev)
-sampler = jatsr_amd.Sampler(model, a.B, a.T, 50, 3.0)
-for _ in range(2):
+sampler = jatsr_amd.Sampler(model, a.B, a.T, a.steps, 3.0)
+out = None
+for _ in range(a.warmup):
     out = sampler.run(lr, z0)
 torch.cuda.synchronize()
 ts = []
