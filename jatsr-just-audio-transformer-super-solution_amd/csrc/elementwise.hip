@@ -603,6 +603,14 @@ __global__ void __launch_bounds__(512) splitk_resid_norm_block_kernel(const floa
     for (int i = 0; i < nw; ++i) t += red[slot][i];
     return t;
   };
+  // the norm weight and this sample's modulation do not depend on the row statistics: requested before the block reduction
+  // (its barrier), not after it — one L2 round trip less on the critical path of a launch that is all latency at small M
+  const f32x4_e ww = (mode == 0 && w) ? *(const f32x4_e*)(w + col) : f32x4_e{1.f, 1.f, 1.f, 1.f};
+  f32x4_e ma = f32x4_e{0.f, 0.f, 0.f, 0.f}, ms = f32x4_e{0.f, 0.f, 0.f, 0.f};
+  if (scale) {
+    ma = *(const f32x4_e*)(scale + (int64_t)b * mod_bstride + col);
+    ms = *(const f32x4_e*)(shift + (int64_t)b * mod_bstride + col);
+  }
   float mu = 0.f, rstd = 1.f;
   if (mode == 0) {
     rstd = rsqrtf(block_sum(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3], 0) / (float)D + 1e-6f);
@@ -613,13 +621,8 @@ __global__ void __launch_bounds__(512) splitk_resid_norm_block_kernel(const floa
     for (int e = 0; e < 4; ++e) var += (xv[e] - mu) * (xv[e] - mu);
     rstd = rsqrtf(block_sum(var, 1) / (float)D + 1e-6f);
   }
-  const f32x4_e ww = (mode == 0 && w) ? *(const f32x4_e*)(w + col) : f32x4_e{1.f, 1.f, 1.f, 1.f};
   f32x4_e t = (xv - mu) * rstd * ww;
-  if (scale) {
-    const f32x4_e a = *(const f32x4_e*)(scale + (int64_t)b * mod_bstride + col);
-    const f32x4_e sft = *(const f32x4_e*)(shift + (int64_t)b * mod_bstride + col);
-    t = t * (1.f + a) + sft;
-  }
+  if (scale) t = t * (1.f + ma) + ms;
   *(uint2*)(y + (int64_t)row * D + col) = pack4_e(t[0], t[1], t[2], t[3]);
 }
 // the fused form exists for widths of 256 .. 2048 in steps of 256 (D / 4 threads = whole waves, at most 8)

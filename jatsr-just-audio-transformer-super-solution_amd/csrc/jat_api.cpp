@@ -451,7 +451,9 @@ static int resid_split(const jat_model* m, const Workspace& w, int site, int M, 
     int split = tiles <= 128 ? 256 / tiles : 1;
     if (split > 2) split = 2;                      // the workspace of this bucket holds two slices (carve)
     while (split > 1 && ((K / 64) % split != 0 || K / split < 512)) --split;
-    if (split > 1 && (K >= 4096 || kpair_split >= 2)) { *variant = 39; return split; }
+    // only where the slices fill the chip (M = 3136 ... 3584: 224 ... 256 blocks); below that the 128 x 128 slices stay (measured
+    // at M = 3584 only: profiles/r03/forward_B28_kernel_table_kpair_split.txt)
+    if (split > 1 && tiles * split >= 224 && (K >= 4096 || kpair_split >= 2)) { *variant = 39; return split; }
   }
   return K >= 4096 ? slices(20, 2) : 1;
 }
