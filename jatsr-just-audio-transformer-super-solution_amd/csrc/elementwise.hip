@@ -2,6 +2,7 @@
 // All of them stream 16 B per lane (cdna_hip_programming.md Guideline 13) and reduce with 64-wide
 // wavefront shuffles; none is GEMM-shaped.
 #include "jat_kernels.h"
+#include "jat_gelu.h"
 #include "jat_dtype.h"
 #include <cstdlib>
 
@@ -527,6 +528,44 @@ __global__ void __launch_bounds__(256) splitk_resid_finish_kernel(const float* _
 #pragma unroll
   for (int j = 0; j < 4; ++j) xv[j] += g[j] * (acc[j] + b[j]);
   *(f32x4_e*)(x + (int64_t)row * N + c) = xv;
+}
+// ---- finish of a split-K Linear + GELU (the first patch-embed Linear, jat_audiosr_v3.py:221-223: [M, 8192] x [512, 8192]^T is 224
+// tiles of 64 x 128 with 64-128 K-tiles each — one 4-wave block per CU; K slices put two on every CU): slice sum in fixed order,
+// bias, GELU (the epilogue's own expression: jat_gelu.h), bf16.  dual_rows > 0 (CFG sampler, split patch embed): row m gets
+// gelu(sum + bias + dual_add[m]), row m + dual_rows gets gelu(sum + bias) — what EPI_BF16_GELU's dual output writes.
+__global__ void __launch_bounds__(256) splitk_gelu_finish_kernel(const float* __restrict__ part, int nsplit, int64_t stride,
+                                                                 const float* __restrict__ bias, const float* __restrict__ dual_add,
+                                                                 int dual_rows, bf16_t* __restrict__ out, int64_t ldo, int M, int N) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread = 4 columns
+  const int per_row = N / 4;
+  if (i >= (int64_t)M * per_row) return;
+  const int row = (int)(i / per_row), c = (int)(i % per_row) * 4;
+  f32x4_e acc = *(const f32x4_e*)(part + (int64_t)row * N + c);
+  for (int z = 1; z < nsplit; ++z) {
+    const f32x4_e v = *(const f32x4_e*)(part + (int64_t)z * stride + (int64_t)row * N + c);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  const f32x4_e b = bias ? *(const f32x4_e*)(bias + c) : f32x4_e{0.f, 0.f, 0.f, 0.f};
+  acc = acc + b;
+  if (dual_rows > 0) {
+    const f32x4_e d = *(const f32x4_e*)(dual_add + (int64_t)row * N + c);
+    f32x2 g[4] = {f32x2{acc[0] + d[0], acc[1] + d[1]}, f32x2{acc[2] + d[2], acc[3] + d[3]}, f32x2{acc[0], acc[1]}, f32x2{acc[2], acc[3]}};
+    gelu_erf_n<4>(g);
+    *(uint2*)(out + (int64_t)row * ldo + c) = pack4_e(g[0][0], g[0][1], g[1][0], g[1][1]);
+    *(uint2*)(out + (int64_t)(row + dual_rows) * ldo + c) = pack4_e(g[2][0], g[2][1], g[3][0], g[3][1]);
+  } else {
+    f32x2 g[2] = {f32x2{acc[0], acc[1]}, f32x2{acc[2], acc[3]}};
+    gelu_erf_n<2>(g);
+    *(uint2*)(out + (int64_t)row * ldo + c) = pack4_e(g[0][0], g[0][1], g[1][0], g[1][1]);
+  }
+}
+hipError_t launch_splitk_gelu_finish(const float* part, int nsplit, int64_t stride, const float* bias, const float* dual_add,
+                                     int dual_rows, bf16_t* out, int64_t ldo, int M, int N, hipStream_t s) {
+  if (N % 4 != 0 || nsplit < 1 || (dual_rows > 0 && !dual_add)) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)M * (N / 4);
+  hipLaunchKernelGGL(splitk_gelu_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nsplit, stride, bias,
+                     dual_add, dual_rows, out, ldo, M, N);
+  return hipGetLastError();
 }
 // ---- finish of a split-K QKV GEMM (one chunk: M = 256, 56 tiles - five K-slices put 280 blocks on the weights): slice sum in
 // fixed order, RoPE on the pair-interleaved q / k features (gemm.hip EPI_QKV_ROPE: the pair (2d', 2d'+1) of a head holds

@@ -109,7 +109,7 @@ extern "C" int jat_model_create(const jat_config* c, jat_model** out) {
   m->sw.fuse_qkv_attn = env_int("JAT_FUSE_QKV_ATTN", 1); m->sw.qkv_split = env_int("JAT_QKV_SPLIT", 1);
   m->sw.fuse_finish = env_int("JAT_FUSE_FINISH", 1); m->sw.fold_norm = env_int("JAT_FOLD_NORM", 1);
   m->sw.split_patch = env_int("JAT_SPLIT_PATCH", 1); m->sw.gemm_dbg = env_int("JAT_GEMM_DBG", 0);
-  m->sw.fold_cap_mb = env_int("JAT_FOLD_CAP_MB", 0);
+  m->sw.fold_cap_mb = env_int("JAT_FOLD_CAP_MB", 0); m->sw.patch_split = env_int("JAT_PATCH_SPLIT", 1);
   if (const char* v = getenv("JAT_GEMM_VARIANT"))
     for (int i = 0; i < 5; ++i) m->variants[i] = atoi(v);
   if (const char* v = getenv("JAT_GEMM_VARIANTS")) {  // "qkv,out,fc1,fc2,other"
@@ -126,7 +126,7 @@ extern "C" int jat_model_set_switch(jat_model* m, const char* name, int32_t valu
   const std::string n(name);
   int* slot = n == "fuse_qkv_attn" ? &m->sw.fuse_qkv_attn : n == "qkv_split" ? &m->sw.qkv_split : n == "fuse_finish" ? &m->sw.fuse_finish
             : n == "fold_norm" ? &m->sw.fold_norm : n == "split_patch" ? &m->sw.split_patch : n == "gemm_dbg" ? &m->sw.gemm_dbg
-            : n == "fold_cap_mb" ? &m->sw.fold_cap_mb : nullptr;
+            : n == "fold_cap_mb" ? &m->sw.fold_cap_mb : n == "patch_split" ? &m->sw.patch_split : nullptr;
   if (!slot) return fail(JAT_E_INVALID, "unknown switch '%s'", name);
   *slot = value;
   return JAT_OK;
@@ -595,20 +595,51 @@ static int forward_impl(const jat_model* m, const Workspace& w, const float* x_t
   // sampler zeroes its private buffer once at creation (mod != nullptr path) and only the generic entry point,
   // whose workspace belongs to the caller, clears it per call.
   if (t) HIPCHK(hipMemsetAsync(w.vt, 0, w.vt_bytes, s));
+  // The first patch-embed Linear is narrow and deep ([rows, 4096 or 8192] x [512, .]^T: 64 x 128 tiles make at most one 4-wave
+  // block per CU at the bench's batch, each walking 64-128 K-tiles): K slices put two blocks on every CU, the finishing pass
+  // adds bias and GELU (same expression as the epilogue).  The partials live in the MLP hidden buffer, idle until block 0's fc1.
+  auto patch_split = [&](int rows, int K) {
+    if (!m->sw.patch_split || m->variants[G_OTHER] >= 0 || m->bott % 128 != 0) return 1;
+    const int tiles = ((rows + 63) / 64) * (m->bott / 128);
+    // measured (profiles/r03/patch_embed_split_ab.log): pays for the single forward (K = 8192: 5.45 -> 5.41 ms) and for one chunk
+    // (24 tiles: 133.4 -> 131.9 ms), not for the sampler's half-depth form at the bench's batch (224 tiles, K = 4096: 353.1 vs 353.6 ms)
+    if (tiles > 128 && K < 8192) return 1;
+    int split = 512 / tiles, cap = m->mlp / (2 * m->bott);   // partial slices must fit w.hm: split * bott * 4 <= mlp * 2 bytes per row
+    if (cap > 4) cap = 4;
+    if (split > cap) split = cap;
+    while (split > 1 && ((K / 64) % split != 0 || K / split < 1024)) --split;
+    return split > 1 ? split : 1;
+  };
   if (pc) {
     // CFG sampler: the first patch-embed Linear is linear in [z ; cond], the z part is the same for the cond and
     // uncond halves and the cond part (pc = patch(lr) @ W1[:, cond]^T, fp32) does not change over the 50 steps:
     // h_cond = gelu(S_z + pc + b1), h_uncond = gelu(S_z + b1) from ONE quarter-size GEMM (M/2 rows, K/2 deep).
     const int Mh = M / 2, Kz = m->P * m->Cin;
     KCHK(launch_patchify(x_t, nullptr, w.a_patch, B_src, B_src, B_src, m->Cin, 0, T, ntok, s, w.tvalid));
-    GemmArgs e{};
-    e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok; e.dual_add = pc; e.dual_rows = Mh;
-    JCHK(gemm(m, G_OTHER, w.a_patch, Kz, m->pe_w1, m->Kp, Mh, m->bott, Kz, EPI_BF16_GELU, e, s));
+    const int ps = patch_split(Mh, Kz);
+    if (ps > 1) {
+      GemmArgs e{};
+      e.out = w.hm; e.ldo = m->bott; e.ntok = ntok; e.ksplit = ps; e.split_stride = (int64_t)Mh * m->bott;
+      JCHK(gemm(m, G_OTHER, w.a_patch, Kz, m->pe_w1, m->Kp, Mh, m->bott, Kz, EPI_F32, e, s));
+      KCHK(launch_splitk_gelu_finish((const float*)w.hm, ps, (int64_t)Mh * m->bott, m->pe_b1, pc, Mh, w.h_patch, m->bott, Mh, m->bott, s));
+    } else {
+      GemmArgs e{};
+      e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok; e.dual_add = pc; e.dual_rows = Mh;
+      JCHK(gemm(m, G_OTHER, w.a_patch, Kz, m->pe_w1, m->Kp, Mh, m->bott, Kz, EPI_BF16_GELU, e, s));
+    }
   } else {
     KCHK(launch_patchify(x_t, x_cond, w.a_patch, B, B_src, cond_zero_from, m->Cin, m->Cc, T, ntok, s, w.tvalid));
-    GemmArgs e{};
-    e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok;
-    JCHK(gemm(m, G_OTHER, w.a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16_GELU, e, s));
+    const int ps = patch_split(M, m->Kp);
+    if (ps > 1) {
+      GemmArgs e{};
+      e.out = w.hm; e.ldo = m->bott; e.ntok = ntok; e.ksplit = ps; e.split_stride = (int64_t)M * m->bott;
+      JCHK(gemm(m, G_OTHER, w.a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_F32, e, s));
+      KCHK(launch_splitk_gelu_finish((const float*)w.hm, ps, (int64_t)M * m->bott, m->pe_b1, nullptr, 0, w.h_patch, m->bott, M, m->bott, s));
+    } else {
+      GemmArgs e{};
+      e.out = w.h_patch; e.ldo = m->bott; e.bias = m->pe_b1; e.ntok = ntok;
+      JCHK(gemm(m, G_OTHER, w.a_patch, m->Kp, m->pe_w1, m->Kp, M, m->bott, m->Kp, EPI_BF16_GELU, e, s));
+    }
   }
   {
     GemmArgs e{};
@@ -1013,7 +1044,6 @@ extern "C" int jat_sampler_info(const jat_sampler* sp, int32_t* folded, int32_t*
 extern "C" int jat_sampler_set_lengths(jat_sampler* sp, const int32_t* frames, int32_t n, void* stream) {
   if (!sp || !frames) return fail(JAT_E_INVALID, "null argument");
   if (n != sp->B) return fail(JAT_E_INVALID, "need one length per batch row (%d), got %d", sp->B, n);
-  const int ntok = (sp->T + 3) / 4;
   std::vector<int> tok((size_t)sp->Bf);
   bool all_full = true;
   for (int b = 0; b < sp->B; ++b) {

@@ -64,6 +64,7 @@ struct jat_switches {
   int split_patch = 1;     // JAT_SPLIT_PATCH:   CFG sampler: condition half of the first patch-embed Linear computed once per run
   int gemm_dbg = 0;        // JAT_GEMM_DBG:      timing aids of gemm.hip (wrong results); 0 in production
   int fold_cap_mb = 0;     // JAT_FOLD_CAP_MB:   upper bound on the folded-weight table (0 = none); beyond it the sampler keeps the norm kernels
+  int patch_split = 1;     // JAT_PATCH_SPLIT:   first patch-embed Linear as K slices + bias/GELU finishing pass when its tiles leave CU slots empty
 };
 // measurement aid (bench.py roofline leg): HIP-event brackets around the launches of one GEMM call site of THIS model
 struct GemmProf {

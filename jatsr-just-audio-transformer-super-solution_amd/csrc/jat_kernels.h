@@ -113,6 +113,9 @@ hipError_t launch_time_sinusoid(const float* t, float* e, int B, int D, hipStrea
 hipError_t launch_linear_f32(const float* in, const float* W, const float* bias, float* out,
                              bf16_t* out_silu_bf16, int B, int N, int K, int act_out, hipStream_t s);
 // x[m][n] += gate[b][n] * (sum_z part[z*stride + m*N + n] + bias[n])   — finish of a split-K gated-residual GEMM
+// finish of a split-K Linear + GELU: out bf16 = gelu(sum_z part[z] + bias (+ dual_add)); dual_rows > 0: rows m and m + dual_rows
+hipError_t launch_splitk_gelu_finish(const float* part, int nsplit, int64_t stride, const float* bias, const float* dual_add,
+                                     int dual_rows, bf16_t* out, int64_t ldo, int M, int N, hipStream_t s);
 // finish of a split-K QKV GEMM: slice sum, RoPE, bf16 q / k rows and transposed V^T (what EPI_QKV_ROPE writes)
 hipError_t launch_splitk_qkv_finish(const float* part, int nsplit, int64_t stride, const float* rope_cos, const float* rope_sin,
                                     bf16_t* q, bf16_t* k, bf16_t* vt, int M, int D, int kvD, int ntok, int npad, hipStream_t s);
