@@ -371,10 +371,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   static const int kvb_env = getenv("JAT_ATTN_KVB") ? atoi(getenv("JAT_ATTN_KVB")) : 64;
   static const int group_env = getenv("JAT_ATTN_GROUP") ? atoi(getenv("JAT_ATTN_GROUP")) : 1;
   static const int qt_env = getenv("JAT_ATTN_QT") ? atoi(getenv("JAT_ATTN_QT")) : 0;   // 0: by block count
-  // 32 queries per wave (QT = 2) halve the K/V traffic per query, but one chunk (B = 2 with CFG, N = 345) then makes 120 blocks
-  // for 256 CUs: below one block per CU take 16 queries per wave
-  const long blocks2 = (long)((a.N + 127) / 128) * a.Hq * a.B;
-  const int qt = qt_env ? qt_env : (blocks2 < 256 ? 1 : 2);
+  // 16 queries per wave (QT = 1).  32 per wave halve the K/V staging per query, but the kernel is bound by the per-element softmax
+  // (and dropout-hash) VALU work of a wave, not by staging, and twice the blocks hide each other's barriers better: measured
+  // one chunk (B = 2 with CFG, N = 345: 120 -> 240 blocks) 140.8 -> 134.6 ms, a four-chunk file 243.8 -> 241.4 ms, the training
+  // step (B = 28, N = 345) 62.05 -> 61.39 ms (profiles/r03/single_chunk_attention_qt_sweep.log, attention_qt_long_train.log)
+  const int qt = qt_env ? qt_env : 1;
   dim3 grid((a.N + 64 * qt - 1) / (64 * qt), a.Hq, a.B);
   const bool kvb64 = kvb_env == 64 || a.N <= 64;
   if (group_env && a.N <= 128 && a.npad >= 128 && !a.lse && !a.drop.thresh) {   // the sampler's shape: K/V staged once per KV head (lens honoured)
