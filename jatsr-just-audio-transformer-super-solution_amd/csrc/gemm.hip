@@ -1887,6 +1887,10 @@ static hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
   const int tiles = (a.M / BM) * (a.N / BN);
   int grid = tiles <= 256 ? tiles : (tiles + 1) / 2;            // two tiles per block once the tiles outnumber the CUs
   if (grid < 256 && tiles > 256) grid = 256;
+  // experiment (tools/two_stream_ab.py): two tiles per block already from `half` blocks on, so that two half-batch launches on two
+  // streams occupy 128 CUs each
+  static const int half_env = getenv("JAT_PERSIST_HALF") ? atoi(getenv("JAT_PERSIST_HALF")) : 0;
+  if (half_env > 0 && tiles > half_env && tiles <= 2 * half_env) grid = (tiles + 1) / 2;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
   return hipGetLastError();
 }
