@@ -178,6 +178,11 @@ def main():
     if args.dry_run:
         return dry_run(args)
 
+    if args.mode == "train":
+        # the trainer overlaps the gradient exchange (its own stream) with the backward; with ROCm's default of four hardware
+        # queues two streams of one process can land on the same queue and run one after the other (seen with two sampler
+        # graphs on two streams: profiles/r03/two_stream_half_batches.log) — must be set before the HIP runtime starts
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
 
