@@ -70,6 +70,17 @@ struct jat_trainer {
   bool tn_dw = true;                   // dW straight from token-major operands (JAT_TN_DW=0: transposed copies + gemm_bf16_kernel)
   float* dkv_part = nullptr;           // per-query-head fp32 partials of dK / dV (attention backward)
   int64_t split4_area = 0, split2_area = 0;
+  // Weight gradients on a second stream (JAT_DW_STREAM=1).  dW = dY^T X of a Linear is off the critical path of the backward (nothing
+  // reads it before the gradient norm), while the dX chain in front of it alternates MFMA-bound GEMMs with HBM- / VALU-bound
+  // passes (norm and gate backward, GELU', attention backward): with the dW GEMMs queued beside that chain the chip works on a
+  // GEMM while the chain is in a memory pass.  The four gradient operands a layer hands to its dW GEMMs (dy of the MLP branch,
+  // dh, dy of the attention branch, dqkv) are double-buffered by layer parity, so the chain runs up to one layer ahead of the dW
+  // stream; events order producer -> dW (ready) and dW -> next writer of the same buffer (done).
+  bool dw_async = false;
+  hipStream_t dw_stream = nullptr;
+  hipEvent_t ev_ready[4][2] = {}, ev_done[4][2] = {}, ev_mod[2] = {}, ev_join = nullptr;
+  std::vector<hipEvent_t> ev_layer;    // block l's weight gradients are complete (gates the gradient-ready hook)
+  bf16_t *dy_m[2] = {}, *dh_b[2] = {}, *dy_a[2] = {}, *dq_b[2] = {};
 };
 
 namespace {
@@ -248,42 +259,97 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
   } else {
     KCHK(launch_mse_grad(tr->pred, target, tr->dpred, tr->red_part, tr->scal, (int64_t)B * m->Cin * T, loss_scale, s));
   }
+  // Where a weight gradient runs: on `s` itself, or (dw_async) on the second stream behind an event of the kernel that
+  // finished its gradient operand; `done` is what the next writer of that operand buffer waits for.
+  hipStream_t ws = tr->dw_async ? tr->dw_stream : s;
+  auto dw_begin = [&](hipEvent_t ready) -> int {
+    if (!tr->dw_async) return JAT_OK;
+    HIPCHK(hipEventRecord(ready, s));
+    HIPCHK(hipStreamWaitEvent(ws, ready, 0));
+    return JAT_OK;
+  };
+  auto dw_end = [&](hipEvent_t done) -> int {
+    if (tr->dw_async) HIPCHK(hipEventRecord(done, ws));
+    return JAT_OK;
+  };
+  auto before_write = [&](hipEvent_t done) -> int {   // a never-recorded event does not block
+    if (tr->dw_async) HIPCHK(hipStreamWaitEvent(s, done, 0));
+    return JAT_OK;
+  };
   // final layer: Linear (unpatchify^T is a patchify of dpred) and the un-modulated norm
   KCHK(launch_patchify(tr->dpred, nullptr, tr->dyf, B, B, B, m->Cin, 0, T, ntok, s));
   JCHK(input_grad(tr, tr->dyf, m->Fout, tr->wfinalT, D, tr->dxn, s));
-  JCHK(weight_grad(tr, tr->dyf, m->Fout, tr->xnf, D, G + tr->o_wf, G + tr->o_bf, s));
+  if (tr->dw_async) { HIPCHK(hipEventRecord(tr->ev_join, s)); HIPCHK(hipStreamWaitEvent(ws, tr->ev_join, 0)); }
+  JCHK(weight_grad(tr, tr->dyf, m->Fout, tr->xnf, D, G + tr->o_wf, G + tr->o_bf, ws));
+  if (tr->dw_async) HIPCHK(hipEventRecord(tr->ev_layer[m->depth], ws));
   KCHK(launch_norm_bwd(tr->x[m->depth], tr->dxn, m->final_norm, nullptr, 0, tr->dx, 0, tr->part, tr->dw_part, nullptr, nullptr, 0,
                        tr->rms ? G + tr->o_fn : nullptr, B, D, ntok, mode, s));
-  if (tr->hook) tr->hook(tr->block_lo[m->depth], tr->total - tr->block_lo[m->depth], tr->hook_user);
+  // gradient-ready hook of a block: with the second stream its weight gradients may still be in flight when the chain moves on,
+  // so the hook of block l fires one block later, behind an event of the dW stream (the exchange stream orders itself after `s`)
+  int pending_hook = -1;
+  auto fire_hook = [&](int blk) -> int {
+    if (!tr->hook) return JAT_OK;
+    if (tr->dw_async) HIPCHK(hipStreamWaitEvent(s, tr->ev_layer[blk], 0));
+    tr->hook(tr->block_lo[blk], (blk == m->depth ? tr->total : tr->block_lo[blk + 1]) - tr->block_lo[blk], tr->hook_user);
+    return JAT_OK;
+  };
+  if (tr->dw_async) pending_hook = m->depth; else JCHK(fire_hook(m->depth));
   for (int l = m->depth - 1; l >= 0; --l) {
     TLayer& L = tr->L[l];
+    const int par = l & 1;
+    bf16_t *dy_m = tr->dy_m[par], *dh = tr->dh_b[par], *dy_a = tr->dy_a[par], *dq = tr->dq_b[par];
     const float* mod = tr->mod + (int64_t)l * 6 * D;
     float* dmod = tr->dmod + (int64_t)l * 6 * D;
     // x_out = x_mid + gate_mlp * mlp(norm2(x_mid) * (1 + scale_mlp) + shift_mlp)          jat_audiosr_v3.py:303-306
-    KCHK(launch_gate_bwd(tr->dx, L.y_mlp, mod + 5 * D, mstride, tr->dy, tr->part, dmod + 5 * D, mstride, B, D, ntok,
+    JCHK(before_write(tr->ev_done[0][par]));
+    KCHK(launch_gate_bwd(tr->dx, L.y_mlp, mod + 5 * D, mstride, dy_m, tr->part, dmod + 5 * D, mstride, B, D, ntok,
                          site(tr, l, 4), site(tr, l, 3), s));
-    JCHK(input_grad(tr, tr->dy, D, L.w2T, m->mlp, tr->dh, s));
-    JCHK(weight_grad(tr, tr->dy, D, L.h_post, m->mlp, G + L.o_w2, G + L.o_b2, s));
-    KCHK(launch_gelu_bwd(L.h_pre, tr->dh, (int64_t)M * m->mlp, site(tr, l, 2), s));
-    JCHK(input_grad(tr, tr->dh, m->mlp, L.w1T, D, tr->dxn, s));
-    JCHK(weight_grad(tr, tr->dh, m->mlp, L.xn2, D, G + L.o_w1, G + L.o_b1, s));
+    JCHK(before_write(tr->ev_done[1][par]));
+    JCHK(input_grad(tr, dy_m, D, L.w2T, m->mlp, dh, s));
+    JCHK(dw_begin(tr->ev_ready[0][par]));
+    JCHK(weight_grad(tr, dy_m, D, L.h_post, m->mlp, G + L.o_w2, G + L.o_b2, ws));
+    JCHK(dw_end(tr->ev_done[0][par]));
+    KCHK(launch_gelu_bwd(L.h_pre, dh, (int64_t)M * m->mlp, site(tr, l, 2), s));
+    JCHK(input_grad(tr, dh, m->mlp, L.w1T, D, tr->dxn, s));
+    JCHK(dw_begin(tr->ev_ready[1][par]));
+    JCHK(weight_grad(tr, dh, m->mlp, L.xn2, D, G + L.o_w1, G + L.o_b1, ws));
+    JCHK(dw_end(tr->ev_done[1][par]));
     KCHK(launch_norm_bwd(L.x_mid, tr->dxn, m->layers[l].norm2, mod + 4 * D, mstride, tr->dx, 1, tr->part, tr->dw_part, dmod + 3 * D,
                          dmod + 4 * D, mstride, tr->rms ? G + L.o_n2 : nullptr, B, D, ntok, mode, s));
     // x_mid = x_in + gate_msa * out_proj(attn(norm1(x_in) * (1 + scale_msa) + shift_msa))   :297-300
-    KCHK(launch_gate_bwd(tr->dx, L.y_attn, mod + 2 * D, mstride, tr->dy, tr->part, dmod + 2 * D, mstride, B, D, ntok,
+    JCHK(before_write(tr->ev_done[2][par]));
+    KCHK(launch_gate_bwd(tr->dx, L.y_attn, mod + 2 * D, mstride, dy_a, tr->part, dmod + 2 * D, mstride, B, D, ntok,
                          site(tr, l, 1), kNoDrop, s));
-    JCHK(input_grad(tr, tr->dy, D, L.woT, D, tr->dao, s));
-    JCHK(weight_grad(tr, tr->dy, D, L.ao, D, G + L.o_o, nullptr, s));
-    KCHK(launch_attention_bwd(L.q, L.k, L.vt, L.ao, tr->dao, L.lse, tr->delta, tr->dqkv, m->rope_cos, m->rope_sin, B, ntok,
+    JCHK(input_grad(tr, dy_a, D, L.woT, D, tr->dao, s));
+    JCHK(dw_begin(tr->ev_ready[2][par]));
+    JCHK(weight_grad(tr, dy_a, D, L.ao, D, G + L.o_o, nullptr, ws));
+    JCHK(dw_end(tr->ev_done[2][par]));
+    JCHK(before_write(tr->ev_done[3][par]));
+    KCHK(launch_attention_bwd(L.q, L.k, L.vt, L.ao, tr->dao, L.lse, tr->delta, dq, m->rope_cos, m->rope_sin, B, ntok,
                               m->Hq, m->Hkv, tr->npad, site(tr, l, 0), tr->dkv_part, s));
-    JCHK(input_grad(tr, tr->dqkv, Nqkv, L.wqkvT, D, tr->dxn, s));
-    JCHK(weight_grad(tr, tr->dqkv, Nqkv, L.xn1, D, tr->dwqkv, nullptr, s));
-    KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, s));
+    JCHK(input_grad(tr, dq, Nqkv, L.wqkvT, D, tr->dxn, s));
+    JCHK(dw_begin(tr->ev_ready[3][par]));
+    JCHK(weight_grad(tr, dq, Nqkv, L.xn1, D, tr->dwqkv, nullptr, ws));
+    KCHK(launch_unpack_qkv_grad(tr->dwqkv, G + L.o_q, G + L.o_k, G + L.o_v, D, m->kvD, D, ws));
+    JCHK(dw_end(tr->ev_done[3][par]));
     KCHK(launch_norm_bwd(tr->x[l], tr->dxn, m->layers[l].norm1, mod + 1 * D, mstride, tr->dx, 1, tr->part, tr->dw_part, dmod + 0 * D,
                          dmod + 1 * D, mstride, tr->rms ? G + L.o_n1 : nullptr, B, D, ntok, mode, s));
-    // adaLN modulation Linear(SiLU(t_emb)) of this block (:275-278): its six dmod slices are complete now
-    KCHK(launch_small_dw(dmod, mstride, tr->t_emb, D, G + L.o_ada_w, G + L.o_ada_b, B, 6 * D, D, 1, s));
-    if (tr->hook) tr->hook(tr->block_lo[l], tr->block_lo[l + 1] - tr->block_lo[l], tr->hook_user);
+    // adaLN modulation Linear(SiLU(t_emb)) of this block (:275-278): its six dmod slices are complete now (a weight gradient
+    // like the others: nothing in the chain reads it)
+    JCHK(dw_begin(tr->ev_mod[par]));
+    KCHK(launch_small_dw(dmod, mstride, tr->t_emb, D, G + L.o_ada_w, G + L.o_ada_b, B, 6 * D, D, 1, ws));
+    if (tr->dw_async) HIPCHK(hipEventRecord(tr->ev_layer[l], ws));
+    if (tr->dw_async) {
+      if (pending_hook >= 0) JCHK(fire_hook(pending_hook));
+      pending_hook = l;
+    } else {
+      JCHK(fire_hook(l));
+    }
+  }
+  if (tr->dw_async) {   // join: everything below (and the optimiser) runs on `s` alone again and may reuse the dW scratch
+    HIPCHK(hipEventRecord(tr->ev_join, ws));
+    HIPCHK(hipStreamWaitEvent(s, tr->ev_join, 0));
+    if (pending_hook >= 0) JCHK(fire_hook(pending_hook));
   }
   // patch embed: Linear(Kp -> bott) - GELU - Linear(bott -> D)   (jat_audiosr_v3.py:221-225); no gradient to the input
   KCHK(launch_cast_bf16(tr->dx, tr->dy, (int64_t)M * D, s));
@@ -305,6 +371,15 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
 
 extern "C" void jat_trainer_destroy(jat_trainer* tr) {
   if (!tr) return;
+  if (tr->dw_stream) { (void)hipStreamSynchronize(tr->dw_stream); (void)hipStreamDestroy(tr->dw_stream); }
+  for (int k = 0; k < 4; ++k)
+    for (int q = 0; q < 2; ++q) {
+      if (tr->ev_ready[k][q]) (void)hipEventDestroy(tr->ev_ready[k][q]);
+      if (tr->ev_done[k][q]) (void)hipEventDestroy(tr->ev_done[k][q]);
+    }
+  if (tr->ev_join) (void)hipEventDestroy(tr->ev_join);
+  for (int q = 0; q < 2; ++q) if (tr->ev_mod[q]) (void)hipEventDestroy(tr->ev_mod[q]);
+  for (hipEvent_t e : tr->ev_layer) if (e) (void)hipEventDestroy(e);
   if (tr->blob) (void)hipFree(tr->blob);
   delete tr;
 }
@@ -396,6 +471,23 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
   if (rc != JAT_OK) { delete tr; return rc; }
 
   if (const char* e = getenv("JAT_TN_DW")) tr->tn_dw = atoi(e) != 0;
+  tr->dw_async = true;   // measured: 61.2 -> 58.5 ms per step at T = 1378, 33.3 -> 31.5 ms at T = 512 (profiles/r03/train_dw_stream_ab.log)
+  if (const char* e = getenv("JAT_DW_STREAM")) tr->dw_async = atoi(e) != 0;
+  if (tr->dw_async) {
+    // lowest priority: when both queues have a GEMM ready, the chain's (critical path) goes first
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    static const int prio_env = getenv("JAT_DW_STREAM_PRIO") ? atoi(getenv("JAT_DW_STREAM_PRIO")) : 1;
+    bool ok = (prio_env ? hipStreamCreateWithPriority(&tr->dw_stream, hipStreamNonBlocking, prio_least)
+                        : hipStreamCreateWithFlags(&tr->dw_stream, hipStreamNonBlocking)) == hipSuccess;
+    auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    for (int k = 0; k < 4; ++k)
+      for (int q = 0; q < 2; ++q) { mk(&tr->ev_ready[k][q]); mk(&tr->ev_done[k][q]); }
+    mk(&tr->ev_join); mk(&tr->ev_mod[0]); mk(&tr->ev_mod[1]);
+    tr->ev_layer.assign((size_t)depth + 1, nullptr);
+    for (auto& e : tr->ev_layer) mk(&e);
+    if (!ok) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "stream / event creation for the weight-gradient stream failed"); }
+  }
   // ---- one allocation: transposed weights, saved activations, backward scratch ----
   for (int pass = 0; pass < 2; ++pass) {
     size_t o = 0;
@@ -458,6 +550,13 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     tr->copy_jobs = (CopyJob*)take((size_t)(8 + 5 * depth + 2) * sizeof(CopyJob));
     tr->dy = (bf16_t*)take(MD2); tr->dh = (bf16_t*)take((size_t)M * std::max(mlp, bott) * 2);
     tr->dxn = (bf16_t*)take(MD2); tr->dao = (bf16_t*)take(MD2); tr->dqkv = (bf16_t*)take((size_t)M * Nqkv * 2);
+    tr->dy_m[0] = tr->dy_a[0] = tr->dy; tr->dy_m[1] = tr->dy_a[1] = tr->dy;   // one stream: every operand has one home
+    tr->dh_b[0] = tr->dh_b[1] = tr->dh; tr->dq_b[0] = tr->dq_b[1] = tr->dqkv;
+    if (tr->dw_async) {   // second home per operand (layer parity) + a separate one for the attention branch's dy: + ~0.4 GB at T = 1378
+      tr->dy_m[1] = (bf16_t*)take(MD2); tr->dy_a[0] = (bf16_t*)take(MD2); tr->dy_a[1] = (bf16_t*)take(MD2);
+      tr->dh_b[1] = (bf16_t*)take((size_t)M * std::max(mlp, bott) * 2);
+      tr->dq_b[1] = (bf16_t*)take((size_t)M * Nqkv * 2);
+    }
     tr->dyf = (bf16_t*)take((size_t)M * m->Fout * 2);
     const int rowsA = std::max(std::max(m->Fout, Nqkv), std::max(mlp, std::max(D, bott)));
     const int rowsB = std::max(std::max(m->Kp, mlp), std::max(D, bott));
