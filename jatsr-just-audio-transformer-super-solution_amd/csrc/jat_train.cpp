@@ -78,7 +78,7 @@ struct jat_trainer {
   // stream; events order producer -> dW (ready) and dW -> next writer of the same buffer (done).
   bool dw_async = false;
   hipStream_t dw_stream = nullptr;
-  hipEvent_t ev_ready[4][2] = {}, ev_done[4][2] = {}, ev_mod[2] = {}, ev_join = nullptr;
+  hipEvent_t ev_ready[4][2] = {}, ev_done[4][2] = {}, ev_mod[2] = {}, ev_join = nullptr, ev_wt = nullptr;
   std::vector<hipEvent_t> ev_layer;    // block l's weight gradients are complete (gates the gradient-ready hook)
   bf16_t *dy_m[2] = {}, *dh_b[2] = {}, *dy_a[2] = {}, *dq_b[2] = {};
 };
@@ -125,6 +125,15 @@ int repack(jat_trainer* tr, hipStream_t s) {
     KCHK(launch_cast_bf16(P + L.o_w1, W.w1, (int64_t)mlp * D, s));
     KCHK(launch_cast_bf16(P + L.o_w2, W.w2, (int64_t)D * mlp, s));
     KCHK(launch_cast_bf16(P + L.o_ada_w, m->wada + (int64_t)l * 6 * D * D, (int64_t)6 * D * D, s));
+  }
+  if (tr->dw_async) {
+    // the transposed copies are read by the NEXT backward only (dX = dY W): rebuilt on the second stream, under the next forward
+    // (HBM-bound copies beside MFMA-bound GEMMs); backward_train waits for ev_wt before its first dX GEMM
+    HIPCHK(hipEventRecord(tr->ev_join, s));
+    HIPCHK(hipStreamWaitEvent(tr->dw_stream, tr->ev_join, 0));
+    JCHK(build_transposes(tr, tr->dw_stream));
+    HIPCHK(hipEventRecord(tr->ev_wt, tr->dw_stream));
+    return JAT_OK;
   }
   return build_transposes(tr, s);
 }
@@ -278,6 +287,7 @@ int backward_train(jat_trainer* tr, const float* target, const float* cond_clean
   };
   // final layer: Linear (unpatchify^T is a patchify of dpred) and the un-modulated norm
   KCHK(launch_patchify(tr->dpred, nullptr, tr->dyf, B, B, B, m->Cin, 0, T, ntok, s));
+  if (tr->dw_async) HIPCHK(hipStreamWaitEvent(s, tr->ev_wt, 0));   // the transposed weight copies of the last re-pack (repack())
   JCHK(input_grad(tr, tr->dyf, m->Fout, tr->wfinalT, D, tr->dxn, s));
   if (tr->dw_async) { HIPCHK(hipEventRecord(tr->ev_join, s)); HIPCHK(hipStreamWaitEvent(ws, tr->ev_join, 0)); }
   JCHK(weight_grad(tr, tr->dyf, m->Fout, tr->xnf, D, G + tr->o_wf, G + tr->o_bf, ws));
@@ -378,6 +388,7 @@ extern "C" void jat_trainer_destroy(jat_trainer* tr) {
       if (tr->ev_done[k][q]) (void)hipEventDestroy(tr->ev_done[k][q]);
     }
   if (tr->ev_join) (void)hipEventDestroy(tr->ev_join);
+  if (tr->ev_wt) (void)hipEventDestroy(tr->ev_wt);
   for (int q = 0; q < 2; ++q) if (tr->ev_mod[q]) (void)hipEventDestroy(tr->ev_mod[q]);
   for (hipEvent_t e : tr->ev_layer) if (e) (void)hipEventDestroy(e);
   if (tr->blob) (void)hipFree(tr->blob);
@@ -483,7 +494,7 @@ extern "C" int jat_trainer_create(jat_model* m, const jat_tensor_ref* params, in
     auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
     for (int k = 0; k < 4; ++k)
       for (int q = 0; q < 2; ++q) { mk(&tr->ev_ready[k][q]); mk(&tr->ev_done[k][q]); }
-    mk(&tr->ev_join); mk(&tr->ev_mod[0]); mk(&tr->ev_mod[1]);
+    mk(&tr->ev_join); mk(&tr->ev_wt); mk(&tr->ev_mod[0]); mk(&tr->ev_mod[1]);
     tr->ev_layer.assign((size_t)depth + 1, nullptr);
     for (auto& e : tr->ev_layer) mk(&e);
     if (!ok) { jat_trainer_destroy(tr); return fail(JAT_E_HIP, "stream / event creation for the weight-gradient stream failed"); }
