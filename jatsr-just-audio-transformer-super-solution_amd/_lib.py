@@ -9,6 +9,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The trainer queues its weight-gradient GEMMs on a second stream beside the backward's dX chain, and exchanges gradients on a
+# third.  ROCm maps a process's streams onto four hardware queues by default: with a few more streams alive (samplers own one
+# each) the second stream can land on the queue of the first, and the step then runs SLOWER than on one stream (measured: 59 ->
+# 88 ms).  Eight queues keep them apart.  Only effective before the HIP runtime starts (importing torch does not start it); an
+# explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # JAT_OPERAND_DTYPE=fp16 selects the fp16-operand build of the same kernels for the whole process (the v3mod2 trainer's
 # autocast dtype, train_ddp_v3mod2.py:854); JAT_LIB_PATH overrides everything (A/B of two builds)
 OPERAND_DTYPE = os.environ.get("JAT_OPERAND_DTYPE", "bf16").lower()

@@ -156,6 +156,10 @@ class Trainer:
         prev = model.__dict__.get("_jat_trainer")
         if prev is not None and prev() is not None:
             prev()._detached = True      # the model's parameters move to THIS trainer's flat buffer: the old one must not step
+            prev()._release()            # and its C side (15-28 GB of workspace, its second stream and events) goes now, not at GC
+            ph = getattr(prev(), "_handle", None)
+            if ph is not None:
+                ph.trainer = None
         self._detached = False
         import torch.distributed as dist
         rank = dist.get_rank(process_group) if (distributed and dist.is_available() and dist.is_initialized()) else 0
@@ -274,10 +278,16 @@ class Trainer:
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
         return x ^ (x >> 31)
 
+    def _release(self):
+        """Destroy the C-side trainer (workspace, streams, events).  The flat torch buffers stay with their owners."""
+        if getattr(self, "ptr", None):
+            torch.cuda.synchronize(self.device)     # nothing of this trainer may still be in flight on any stream
+            L.lib().jat_trainer_destroy(self.ptr)
+            self.ptr = None
+
     def __del__(self):
         try:
-            if getattr(self, "ptr", None):
-                L.lib().jat_trainer_destroy(self.ptr)
+            self._release()
         except Exception:
             pass
 
@@ -480,6 +490,8 @@ class Trainer:
         """The fp32 master weights were overwritten from outside an optimiser step (checkpoint, load_state_dict): rebuild
         every operand copy (bf16, transposed) and make dependants stale.  Synchronous: a sampler created next builds its
         tables on a private stream and must see the finished copies."""
+        if self._detached or not self.ptr:      # superseded: the newer Trainer owns the weights and re-packs them itself
+            return
         L.check(L.lib().jat_trainer_repack(self.ptr, L.stream_ptr()))
         torch.cuda.current_stream().synchronize()
         self._handle.epoch += 1

@@ -81,6 +81,31 @@ def test_train_step_vs_reference_golden(name):
     _check_step_vs_golden(name, with_adamw=True)
 
 
+def test_weight_gradient_stream_is_bit_identical_to_program_order(monkeypatch):
+    """The trainer queues the weight-gradient GEMMs (and, after an optimiser step, the transposed weight copies) on its own
+    stream beside the dX chain, with the gradient operands double-buffered by layer parity (JAT_DW_STREAM=0 keeps
+    everything on the caller's stream).  Same kernels, same summation orders: after TWO full steps (the second one reads the
+    transposed copies the first one's re-pack built on the second stream) loss, every gradient and every parameter must be
+    bit-equal between the two forms."""
+    z, meta = load_golden("train_tiny_T128")
+    hr, lr, noise, t, mask = step_inputs(meta)
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("JAT_DW_STREAM", mode)       # read in jat_trainer_create
+        m, tr = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+        for _ in range(2):
+            z_t, t2, cond = tr.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+            tr.forward_backward(z_t, t2, cond, hr)
+            g = tr.grads.clone()
+            tr.optimizer_step()
+        torch.cuda.synchronize()
+        res.append((float(tr._scal[0]), g, tr.params.clone()))
+        del tr, m
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert float(res[0][1].abs().sum()) > 0
+
+
 BIG_CASES = ["train_v3mod2_T128", "train_v3mod2_T70_ragged"]
 
 
