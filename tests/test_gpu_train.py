@@ -81,6 +81,32 @@ def test_train_step_vs_reference_golden(name):
     _check_step_vs_golden(name, with_adamw=True)
 
 
+def test_a_second_trainer_supersedes_the_first_and_frees_its_device_side():
+    """A model has ONE owner of its parameters: constructing a second Trainer re-points them to its own flat buffer.  The first
+    one must refuse to step from then on AND give up its C side at once — workspace (15-28 GB at full size), second stream,
+    events — instead of at some later garbage collection (three benchmark legs in a row once left three trainers' streams
+    alive, and the third one's weight-gradient stream shared a hardware queue with the backward: 59 -> 88 ms per step)."""
+    z, meta = load_golden("train_micro_T24")
+    hr, lr, noise, t, mask = step_inputs(meta)
+    m, first = make_trainer(meta, use_grad_scaler=False, condition_noise_ratio=0.0)
+    z_t, t2, cond = first.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    first.forward_backward(z_t, t2, cond, hr)
+    first.optimizer_step()
+    free_before = torch.cuda.mem_get_info()[0]
+    second = Trainer(m, batch_size=meta["B"], frames=meta["T"], lr=meta["lr"], weight_decay=meta["wd"], grad_clip=meta["clip"],
+                     use_grad_scaler=False, condition_noise_ratio=0.0)
+    assert first._detached and not first.ptr
+    with pytest.raises(L.JatError):
+        first.forward_backward(z_t, t2, cond, hr)
+    z_t, t2, cond = second.prepare(hr, lr, noise=noise, cfg_mask=mask, t=t)
+    second.forward_backward(z_t, t2, cond, hr)          # the survivor works, on the weights the first one left behind
+    second.optimizer_step()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(second._scal[0]))
+    # the second workspace did not come on top of the first: at most one workspace (+ flat buffers) more than before
+    assert free_before - torch.cuda.mem_get_info()[0] < 2 * second.workspace_bytes() + 4 * second.params.numel() * 4 + (64 << 20)
+
+
 def test_weight_gradient_stream_is_bit_identical_to_program_order(monkeypatch):
     """The trainer queues the weight-gradient GEMMs (and, after an optimiser step, the transposed weight copies) on its own
     stream beside the dX chain, with the gradient operands double-buffered by layer parity (JAT_DW_STREAM=0 keeps
