@@ -543,7 +543,8 @@ def main():
                                                 "*_latent_loss: + 0.3 x latent perceptual loss; T1378_v3mod2_V2_latent_loss_fp16: "
                                                 "BASELINE configs[3] as the reference runs it — JaT_AudioSR_V2 (LayerNorm), MSE + latent "
                                                 "loss, fp16 operands + dynamic loss scale (train_ddp_v3mod2.py:706,745,854-896), child "
-                                                "process on libjat_hip_fp16.so; one GPU", **legs}
+                                                "process on libjat_hip_fp16.so; one GPU; weight gradients and the re-pack's "
+                                                "transposed copies run on the trainer's second stream (JAT_DW_STREAM=0: one stream)", **legs}
 
         # ---- CPU baseline: the numpy oracle (port of the reference's fp32 CPU forward, pinned to the
         # reference by tests/golden) on this host's cores: 1 warm-up + 3 timed forwards at B=28, T=512, and the oracle's
