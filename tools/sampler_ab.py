@@ -13,15 +13,18 @@ ap.add_argument("--runs", type=int, default=8)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--tag", default="")
+ap.add_argument("--zero", action="store_true", help="all-zero weights and inputs: same instructions, no operand toggling (power probe)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = recipe.CONFIGS["v3mod2"]
 sd = recipe.make_state_dict(cfg)
 model = jatsr_amd.JaT_AudioSR_V3(**cfg)
-model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+model.load_state_dict({k: torch.from_numpy(v * 0 if a.zero else v) for k, v in sd.items()}, strict=False)
 model = model.to(dev).eval()
 lr = torch.from_numpy(recipe.gaussian("lr_latent", (a.B, 1024, a.T), 1234)).to(dev)
 z0 = torch.from_numpy(recipe.gaussian("z0", (a.B, 1024, a.T), 1235)).to(dev)
+if a.zero:
+    lr, z0 = lr * 0, z0 * 0
 sampler = jatsr_amd.Sampler(model, a.B, a.T, a.steps, 3.0)
 out = None
 for _ in range(a.warmup):
