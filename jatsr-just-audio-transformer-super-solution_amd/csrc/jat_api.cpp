@@ -356,6 +356,13 @@ static int pick_variant(int M, int N, int nbatch = 1) {
     score *= (double)M / (double)(((M + c.bm - 1) / c.bm) * c.bm);
     if (score > best_score) { best_score = score; best = c.id; }
   }
+  // a half-size batch's QKV GEMM (M = 3584, N = 1792): 392 tiles of 128 x 128 fill 77 % of the 512 four-wave slots; 196 tiles of
+  // 256 x 128 with the DMA-wave pipeline are one block on 196 CUs and measured faster (forward 5.530 -> 5.455 ms,
+  // profiles/r03/forward_B28_out_qkv_tile_sweep.log).  Only where those tiles make one nearly full round.
+  if (best == 20 && nbatch == 1 && N % 128 == 0) {
+    const long t26 = (long)((M + 255) / 256) * (N / 128);
+    if (t26 >= 192 && t26 <= 256 && M % 256 == 0) best = 26;
+  }
   // 36: the tile of 31 with the software-pipelined bf16 / GELU epilogue (JAT_EPI_PIPE=0 keeps the plain one: A/B)
   static const int epi_pipe = getenv("JAT_EPI_PIPE") ? atoi(getenv("JAT_EPI_PIPE")) : 1;
   if (epi_pipe && best == 31) best = 36;
