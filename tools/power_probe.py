@@ -8,6 +8,7 @@ import jatsr_amd, jatsr_amd.recipe as recipe
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=12.0)
+ap.add_argument("--train", action="store_true", help="load = the training step (B=28, T=1378) instead of the sampler")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = recipe.CONFIGS["v3mod2"]
@@ -16,8 +17,18 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.make_state_dict
 model = model.to(dev).eval()
 lr = torch.from_numpy(recipe.gaussian("lr_latent", (28, 1024, 512), 1234)).to(dev)
 z0 = torch.from_numpy(recipe.gaussian("z0", (28, 1024, 512), 1235)).to(dev)
-sampler = jatsr_amd.Sampler(model, 28, 512, 50, 3.0)
-sampler.run(lr, z0)
+if a.train:
+    from jatsr_amd.train import Trainer
+    model.train()
+    trainer = Trainer(model, batch_size=28, frames=1378, seed=1, distributed=False)
+    hr_t = torch.from_numpy(recipe.gaussian("train_hr", (28, 1024, 1378), 300)).to(dev)
+    lr_t = torch.from_numpy(recipe.gaussian("train_lr", (28, 1024, 1378), 301)).to(dev)
+    mean, std = torch.zeros(1024, device=dev), torch.ones(1024, device=dev)
+    step = lambda: trainer.train_step(hr_t, lr_t, mean, std, mean, std)
+else:
+    sampler = jatsr_amd.Sampler(model, 28, 512, 50, 3.0)
+    step = lambda: sampler.run(lr, z0)
+step()
 torch.cuda.synchronize()
 
 
@@ -36,7 +47,7 @@ stop = False
 
 def load():
     while not stop:
-        sampler.run(lr, z0)
+        step()
         torch.cuda.synchronize()
 
 
